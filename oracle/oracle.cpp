@@ -1,0 +1,1770 @@
+// oracle.cpp — CPU restatement of trevday/rust-raytracer's path-tracing hot path.
+//
+// TEST INFRASTRUCTURE ONLY.  Nothing under rust_raytracer_amd/ (the product) may
+// include, link, import or execute this file; only tests/, __graft_entry__.smoke()
+// and bench.py's cpu_baseline leg load liboracle.so, and only as the checker / the
+// reported CPU baseline.
+//
+// Parity status: PARITY UNPINNED BY REFERENCE TESTS.  The reference ships no tests,
+// golden vectors or fixtures and cannot be built here (no Rust toolchain), so this
+// restatement is pinned only by (a) hand-checkable known answers in
+// tests/test_oracle_known_answers.py and (b) the statistics of the reference's
+// gallery render img/cornell_box.png recorded in tests/golden/.
+//
+// Every function cites the reference file:line it follows (paths relative to the
+// reference repository root).  Arithmetic is plain IEEE f32, unfused
+// (-ffp-contract=off), in the reference's operand order.
+//
+// Two deliberate, documented departures (neither is pinned by the reference, whose
+// RNG is the unseedable OS-seeded rand 0.7.3 ThreadRng):
+//   1. rand::random::<f32>() is replaced by a counter-based stream keyed by
+//      (seed, pixel, sample) so that a GPU implementation can consume the very
+//      same numbers; the draw *order* follows the reference call order.
+//   2. sin/cos/asin/atan2/ln on the per-ray path use the small deterministic
+//      f32 routines in this file (dm_*) instead of the platform libm, so that
+//      results do not depend on which libm a host or device happens to have.
+//      Host-side scene set-up (camera, rotation matrices) uses libm as Rust does.
+//   3. The one random draw made *inside* traversal (volume.rs:95) is keyed by
+//      (path state, depth, primitive) instead of being taken from the sequential
+//      stream, so its value does not depend on how many BVH nodes were culled.
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace orc {
+
+// ---------------------------------------------------------------------------
+// base.rs / vector.rs / point.rs / color.rs / ray.rs
+// ---------------------------------------------------------------------------
+struct V3 {
+    float x, y, z;
+};
+static inline V3 v3(float x, float y, float z) { return V3{x, y, z}; }
+// base.rs:46-86
+static inline V3 operator+(V3 a, V3 b) { return v3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline V3 operator-(V3 a, V3 b) { return v3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline V3 operator-(V3 a) { return v3(-a.x, -a.y, -a.z); }
+// base.rs:88-128 (component-wise, tuple * scalar, tuple / scalar)
+static inline V3 operator*(V3 a, V3 b) { return v3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline V3 operator*(V3 a, float s) { return v3(a.x * s, a.y * s, a.z * s); }
+// vector.rs:117-126 (f32 * Vector3)
+static inline V3 operator*(float s, V3 a) { return v3(s * a.x, s * a.y, s * a.z); }
+static inline V3 operator/(V3 a, float s) { return v3(a.x / s, a.y / s, a.z / s); }
+// base.rs:29-43 : min/max pick v1 only when strictly smaller/greater
+static inline V3 vmin(V3 a, V3 b) { return v3(a.x < b.x ? a.x : b.x, a.y < b.y ? a.y : b.y, a.z < b.z ? a.z : b.z); }
+static inline V3 vmax(V3 a, V3 b) { return v3(a.x > b.x ? a.x : b.x, a.y > b.y ? a.y : b.y, a.z > b.z ? a.z : b.z); }
+// vector.rs:57-79
+static inline float dot(V3 a, V3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+static inline float sqlen(V3 a) { return (a.x * a.x) + (a.y * a.y) + (a.z * a.z); }
+static inline float length(V3 a) { return std::sqrt(sqlen(a)); }
+static inline V3 normalized(V3 a) { return a / length(a); }
+static inline V3 cross(V3 a, V3 b) {
+    return v3((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x));
+}
+static inline float axis_of(V3 a, int ax) { return ax == 0 ? a.x : (ax == 1 ? a.y : a.z); }
+
+typedef V3 RGB;  // color.rs:9 (same tuple, same operators)
+
+struct Ray {  // ray.rs:4-20
+    V3 origin, dir;
+};
+static inline V3 point_at(const Ray& r, float t) { return r.origin + (r.dir * t); }
+
+static const float kPi = 3.14159265358979323846f;     // f32::consts::PI
+static const float kFracPi2 = 1.57079632679489661923f;  // FRAC_PI_2
+static const float kFrac1Pi = 0.318309886183790671538f; // FRAC_1_PI
+static const float kEps = 1.1920929e-7f;                 // f32::EPSILON
+static const float kTMin = 0.001f;                       // utils.rs:7
+static const float kTMax = std::numeric_limits<float>::max();  // utils.rs:8
+static const float kColorSpace = 255.99f;                // color.rs:6
+
+// utils.rs:51-79
+static inline float clampf(float v, float lo, float hi) { return v > hi ? hi : (v < lo ? lo : v); }
+static inline float float_max(float f, float m) { return f > m ? f : m; }
+static inline float float_min(float f, float m) { return f < m ? f : m; }
+static inline float lerp(float t, float a, float b) { return (1.0f - t) * a + t * b; }
+
+// ---------------------------------------------------------------------------
+// Deterministic f32 elementary functions (departure 2 in the header).
+// Only + - * / sqrt floor and comparisons; every operation is a single
+// correctly-rounded f32 op, so any IEEE machine reproduces the same bits.
+// ---------------------------------------------------------------------------
+static inline void dm_sincos(float x, float* s_out, float* c_out) {
+    // Cody-Waite reduction by pi/2 in three pieces, then degree-7/8 minimax-style
+    // Taylor polynomials on [-pi/4, pi/4].
+    const float two_over_pi = 0.63661977236758134308f;
+    const float c1 = 1.5703125f;                 // 8 significant bits: k*c1 exact for |k| < 2^16
+    const float c2 = 4.837512969970703125e-4f;   // next 11 bits
+    const float c3 = 7.54978995489188e-8f;       // remainder
+    float k = std::floor(x * two_over_pi + 0.5f);
+    float r = ((x - k * c1) - k * c2) - k * c3;
+    float r2 = r * r;
+    // sin(r) = r + r^3 * (S1 + r2*(S2 + r2*(S3 + r2*S4)))
+    float sp = -1.9841270114e-4f + r2 * 2.7557314297e-6f;
+    sp = 8.3333337680e-3f + r2 * sp;
+    sp = -1.6666667163e-1f + r2 * sp;
+    float sr = r + (r * r2) * sp;
+    // cos(r) = 1 - r2/2 + r2^2 * (C1 + r2*(C2 + r2*C3))
+    float cp = -1.3888889225e-3f + r2 * 2.4801587642e-5f;
+    cp = 4.1666667908e-2f + r2 * cp;
+    float cr = (1.0f - 0.5f * r2) + (r2 * r2) * cp;
+    // quadrant = k mod 4, computed in float (exact while |k| < 2^24)
+    float q = k - 4.0f * std::floor(k * 0.25f);
+    float s, c;
+    if (q == 0.0f) { s = sr; c = cr; }
+    else if (q == 1.0f) { s = cr; c = -sr; }
+    else if (q == 2.0f) { s = -sr; c = -cr; }
+    else { s = -cr; c = sr; }
+    *s_out = s;
+    *c_out = c;
+}
+static inline float dm_sin(float x) { float s, c; dm_sincos(x, &s, &c); return s; }
+static inline float dm_cos(float x) { float s, c; dm_sincos(x, &s, &c); return c; }
+
+static inline float dm_atan_poly(float a) {
+    // atan(a) for |a| <= tan(pi/8): odd polynomial (Cephes atanf coefficients).
+    float z = a * a;
+    float p = 8.05374449538e-2f * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    return a + (a * z) * p;
+}
+static inline float dm_atan2(float y, float x) {
+    float ax = x < 0.0f ? -x : x;
+    float ay = y < 0.0f ? -y : y;
+    float hi = ax > ay ? ax : ay;
+    float lo = ax > ay ? ay : ax;
+    float r;
+    if (hi == 0.0f) {
+        r = 0.0f;
+    } else {
+        float a = lo / hi;  // in [0,1]
+        if (a > 0.4142135623730950f) {
+            r = 0.785398163397448309616f + dm_atan_poly((a - 1.0f) / (a + 1.0f));
+        } else {
+            r = dm_atan_poly(a);
+        }
+    }
+    if (ay > ax) r = 1.57079632679489661923f - r;
+    if (x < 0.0f) r = 3.14159265358979323846f - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+static inline float dm_asin(float x) {
+    float a = x < 0.0f ? -x : x;
+    float r;
+    if (a > 1.0f) {
+        r = std::numeric_limits<float>::quiet_NaN();
+    } else if (a > 0.5f) {
+        // asin(a) = pi/2 - 2 asin(sqrt((1-a)/2))
+        float z = 0.5f * (1.0f - a);
+        float s = std::sqrt(z);
+        float p = 4.2163199048e-2f * z + 2.4181311049e-2f;
+        p = p * z + 4.5470025998e-2f;
+        p = p * z + 7.4953002686e-2f;
+        p = p * z + 1.6666752422e-1f;
+        float as = s + (s * z) * p;
+        r = 1.57079632679489661923f - 2.0f * as;
+    } else {
+        float z = a * a;
+        float p = 4.2163199048e-2f * z + 2.4181311049e-2f;
+        p = p * z + 4.5470025998e-2f;
+        p = p * z + 7.4953002686e-2f;
+        p = p * z + 1.6666752422e-1f;
+        r = a + (a * z) * p;
+    }
+    return x < 0.0f ? -r : r;
+}
+static inline float dm_log(float x) {
+    // Natural log for x >= 0 (0 -> -inf, negative -> NaN); normal numbers only
+    // (inputs here are k * 2^-24).
+    if (x < 0.0f) return std::numeric_limits<float>::quiet_NaN();
+    if (x == 0.0f) return -std::numeric_limits<float>::infinity();
+    uint32_t bits;
+    std::memcpy(&bits, &x, 4);
+    int e = (int)((bits >> 23) & 0xffu) - 127;
+    uint32_t mb = (bits & 0x007fffffu) | 0x3f800000u;  // mantissa in [1,2)
+    float m;
+    std::memcpy(&m, &mb, 4);
+    if (m > 1.41421356237f) {
+        m = m * 0.5f;
+        e = e + 1;
+    }
+    // log(m) = 2 atanh(s), s = (m-1)/(m+1), |s| <= 0.1716
+    float s = (m - 1.0f) / (m + 1.0f);
+    float s2 = s * s;
+    float p = 0.2222222222f + s2 * 0.1818181818f;
+    p = 0.2857142857f + s2 * p;
+    p = 0.4f + s2 * p;
+    p = 0.6666666667f + s2 * p;
+    float lm = 2.0f * s + (s * s2) * p;
+    float fe = (float)e;
+    return (fe * 0.693359375f + (fe * -2.12194440054690583e-4f)) + lm;
+}
+
+// ---------------------------------------------------------------------------
+// Random stream (departure 1).  xoroshiro64* seeded by a non-linear hash of
+// (seed, pixel, sample); f32 = top 24 bits * 2^-24 like rand 0.7.3's Standard.
+// ---------------------------------------------------------------------------
+static inline uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+static inline uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+struct Rng {
+    uint32_t s0, s1;
+};
+static inline Rng rng_seed(uint32_t seed, uint32_t pixel, uint32_t sample) {
+    uint32_t a = mix32(pixel ^ mix32(seed));
+    uint32_t b = mix32(sample ^ 0x5bd1e995u);
+    Rng r;
+    r.s0 = mix32(a + b);
+    r.s1 = mix32(b ^ r.s0);
+    if ((r.s0 | r.s1) == 0u) r.s1 = 0x9e3779b9u;
+    return r;
+}
+static inline uint32_t rng_u32(Rng& r) {
+    uint32_t s0 = r.s0, s1 = r.s1;
+    uint32_t out = s0 * 0x9e3779bbu;
+    s1 ^= s0;
+    r.s0 = rotl32(s0, 26) ^ s1 ^ (s1 << 9);
+    r.s1 = rotl32(s1, 13);
+    return out;
+}
+static inline float u32_to_f32(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+static inline float rng_f32(Rng& r) { return u32_to_f32(rng_u32(r)); }
+// Uniform index in [0,n) (SliceRandom::choose, pdf.rs:110).
+static inline uint32_t rng_index(Rng& r, uint32_t n) { return (uint32_t)(((uint64_t)rng_u32(r) * (uint64_t)n) >> 32); }
+// Keyed draw for volume.rs:95 (departure 3).
+static inline float rng_keyed_f32(const Rng& r, uint32_t depth, uint32_t prim) {
+    uint32_t h = mix32(r.s1 + depth * 0x9e3779b9u + prim * 0x85ebca6bu);
+    return u32_to_f32(mix32(r.s0 ^ h));
+}
+
+// ---------------------------------------------------------------------------
+// utils.rs samplers, ONB, Perlin noise
+// ---------------------------------------------------------------------------
+// utils.rs:10-14
+static inline V3 random_unit_disk(Rng& g) {
+    float x = 2.0f * rng_f32(g) - 1.0f;
+    float y = std::sqrt(1.0f - x * x);
+    return v3(x, y, 0.0f);
+}
+// utils.rs:16-24
+static inline V3 unit_sphere_random(Rng& g) {
+    float azimuth = rng_f32(g) * kPi * 2.0f;
+    float y = rng_f32(g);
+    float sin_elevation = std::sqrt(1.0f - y * y);
+    float sa, ca;
+    dm_sincos(azimuth, &sa, &ca);
+    float x = sin_elevation * ca;
+    float z = sin_elevation * sa;
+    return v3(x, y, z);
+}
+// utils.rs:26-36
+static inline V3 random_cosine_direction(Rng& g) {
+    float r1 = rng_f32(g);
+    float r2 = rng_f32(g);
+    float z = std::sqrt(1.0f - r2);
+    float phi = 2.0f * kPi * r1;
+    float sp, cp;
+    dm_sincos(phi, &sp, &cp);
+    float x = cp * std::sqrt(r2);
+    float y = sp * std::sqrt(r2);
+    return v3(x, y, z);
+}
+// utils.rs:38-49
+static inline V3 random_to_sphere(Rng& g, float radius, float distance_squared) {
+    float r1 = rng_f32(g);
+    float r2 = rng_f32(g);
+    float z = 1.0f + r2 * (std::sqrt(float_max(1.0f - radius * radius / distance_squared, 0.0f)) - 1.0f);
+    float phi = 2.0f * kPi * r1;
+    float sp, cp;
+    dm_sincos(phi, &sp, &cp);
+    float x = cp * std::sqrt(float_max(1.0f - z * z, 0.0f));
+    float y = sp * std::sqrt(float_max(1.0f - z * z, 0.0f));
+    return v3(x, y, z);
+}
+
+// utils.rs:82-110 — permutation table (data), duplicated for lookup without wrap.
+static const uint8_t kNoise[256] = {
+    63, 147, 186, 78, 92, 53, 229, 76, 14, 204, 183, 99, 237, 241, 59, 167, 118, 23, 29, 44, 82,
+    37, 6, 249, 131, 253, 210, 28, 71, 96, 3, 207, 115, 32, 158, 61, 215, 220, 116, 40, 48, 93,
+    179, 196, 141, 0, 165, 185, 145, 217, 139, 216, 250, 235, 39, 232, 124, 146, 5, 77, 180, 4, 31,
+    203, 154, 178, 226, 25, 20, 130, 22, 240, 252, 163, 75, 90, 51, 89, 151, 193, 33, 69, 21, 149,
+    208, 244, 238, 191, 161, 36, 38, 81, 181, 56, 43, 127, 34, 243, 65, 200, 97, 247, 79, 231, 98,
+    11, 100, 142, 15, 166, 45, 209, 223, 66, 119, 155, 49, 153, 113, 41, 133, 197, 157, 112, 46,
+    91, 74, 27, 128, 228, 16, 248, 174, 187, 87, 95, 30, 110, 212, 175, 144, 135, 225, 172, 221,
+    170, 67, 9, 111, 224, 239, 176, 117, 109, 177, 202, 132, 80, 125, 62, 251, 108, 148, 103, 227,
+    50, 17, 35, 24, 126, 164, 42, 156, 10, 182, 218, 70, 246, 150, 73, 213, 138, 129, 189, 188, 84,
+    160, 134, 105, 83, 169, 121, 233, 194, 19, 114, 55, 211, 58, 104, 254, 57, 18, 123, 102, 140,
+    8, 171, 68, 206, 168, 86, 136, 152, 47, 60, 88, 101, 26, 122, 13, 192, 94, 198, 64, 234, 195,
+    52, 245, 54, 236, 219, 12, 106, 143, 120, 7, 190, 1, 2, 205, 222, 159, 162, 173, 85, 107, 201,
+    184, 214, 137, 230, 255, 242, 72, 199};
+static inline int noise_data(int i) { return (int)kNoise[i & 255]; }  // index range is [0,511]
+
+// Rust `as i32` from f32 saturates and maps NaN to 0.
+static inline int32_t f32_as_i32(float f) {
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int32_t)f;
+}
+// Rust `as u32` from f32 saturates and maps NaN to 0.
+static inline uint32_t f32_as_u32(float f) {
+    if (f != f) return 0u;
+    if (f <= 0.0f) return 0u;
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+// utils.rs:149-170
+static inline float noise_gradient(int x, int y, int z, float dx, float dy, float dz) {
+    int val = noise_data(noise_data(noise_data(x) + y) + z);
+    val &= 15;
+    float u = (val < 8 || val == 12 || val == 13) ? dx : dy;
+    float v = (val < 4 || val == 12 || val == 13) ? dy : dz;
+    if ((val & 1) > 0) u = -u;
+    if ((val & 2) > 0) v = -v;
+    return u + v;
+}
+// utils.rs:171-175
+static inline float noise_smooth(float f) {
+    float f_3 = f * f * f;
+    float f_4 = f_3 * f;
+    return 6.0f * f_4 * f - 15.0f * f_4 + 10.0f * f_3;
+}
+// utils.rs:112-148
+static inline float noise(V3 p) {
+    int ix = f32_as_i32(std::floor(p.x));
+    int iy = f32_as_i32(std::floor(p.y));
+    int iz = f32_as_i32(std::floor(p.z));
+    float dx = p.x - (float)ix;
+    float dy = p.y - (float)iy;
+    float dz = p.z - (float)iz;
+    ix &= 255;
+    iy &= 255;
+    iz &= 255;
+    float w000 = noise_gradient(ix, iy, iz, dx, dy, dz);
+    float w100 = noise_gradient(ix + 1, iy, iz, dx - 1.0f, dy, dz);
+    float w010 = noise_gradient(ix, iy + 1, iz, dx, dy - 1.0f, dz);
+    float w001 = noise_gradient(ix, iy, iz + 1, dx, dy, dz - 1.0f);
+    float w110 = noise_gradient(ix + 1, iy + 1, iz, dx - 1.0f, dy - 1.0f, dz);
+    float w101 = noise_gradient(ix + 1, iy, iz + 1, dx - 1.0f, dy, dz - 1.0f);
+    float w011 = noise_gradient(ix, iy + 1, iz + 1, dx, dy - 1.0f, dz - 1.0f);
+    float w111 = noise_gradient(ix + 1, iy + 1, iz + 1, dx - 1.0f, dy - 1.0f, dz - 1.0f);
+    float wx = noise_smooth(dx);
+    float wy = noise_smooth(dy);
+    float wz = noise_smooth(dz);
+    float x00 = lerp(wx, w000, w100);
+    float x10 = lerp(wx, w010, w110);
+    float x01 = lerp(wx, w001, w101);
+    float x11 = lerp(wx, w011, w111);
+    float y0 = lerp(wy, x00, x10);
+    float y1 = lerp(wy, x01, x11);
+    return lerp(wz, y0, y1);
+}
+// utils.rs:177-189
+static inline float turbulence(V3 p, uint32_t depth, float omega) {
+    float sum = 0.0f;
+    V3 pc = p;
+    float weight = 1.0f;
+    for (uint32_t i = 0; i < depth; ++i) {
+        sum += weight * noise(pc);
+        weight *= omega;
+        pc = pc * 1.99f;
+    }
+    return std::fabs(sum);
+}
+// utils.rs:191-214 (input is NOT normalised)
+struct ONB {
+    V3 axis[3];
+};
+static inline ONB onb_new(V3 v) {
+    ONB o;
+    o.axis[2] = v;
+    V3 a = std::fabs(v.x) > 0.9f ? v3(0.0f, 1.0f, 0.0f) : v3(1.0f, 0.0f, 0.0f);
+    o.axis[1] = normalized(cross(v, a));
+    o.axis[0] = cross(v, o.axis[1]);
+    return o;
+}
+static inline V3 onb_local(const ONB& o, V3 v) { return (v.x * o.axis[0]) + (v.y * o.axis[1]) + (v.z * o.axis[2]); }
+
+// ---------------------------------------------------------------------------
+// matrix.rs / transform.rs
+// ---------------------------------------------------------------------------
+struct M4 {
+    float d[4][4];
+};
+static inline M4 m4_zero() { M4 m; std::memset(&m, 0, sizeof m); return m; }
+static inline M4 m4_identity() { M4 m = m4_zero(); m.d[0][0] = m.d[1][1] = m.d[2][2] = m.d[3][3] = 1.0f; return m; }
+static inline float to_radians(float deg) { return deg * (kPi / 180.0f); }  // core f32::to_radians
+// matrix.rs:34-84
+static inline M4 m4_translation(V3 t) { M4 m = m4_identity(); m.d[0][3] = t.x; m.d[1][3] = t.y; m.d[2][3] = t.z; return m; }
+static inline M4 m4_rotation_x(float deg) {
+    float s = std::sin(to_radians(deg)), c = std::cos(to_radians(deg));
+    M4 m = m4_identity();
+    m.d[1][1] = c; m.d[1][2] = -s; m.d[2][1] = s; m.d[2][2] = c;
+    return m;
+}
+static inline M4 m4_rotation_y(float deg) {
+    float s = std::sin(to_radians(deg)), c = std::cos(to_radians(deg));
+    M4 m = m4_identity();
+    m.d[0][0] = c; m.d[0][2] = s; m.d[2][0] = -s; m.d[2][2] = c;
+    return m;
+}
+static inline M4 m4_rotation_z(float deg) {
+    float s = std::sin(to_radians(deg)), c = std::cos(to_radians(deg));
+    M4 m = m4_identity();
+    m.d[0][0] = c; m.d[0][1] = -s; m.d[1][0] = s; m.d[1][1] = c;
+    return m;
+}
+static inline M4 m4_scale(V3 s) { M4 m = m4_identity(); m.d[0][0] = s.x; m.d[1][1] = s.y; m.d[2][2] = s.z; return m; }
+// matrix.rs:138-152
+static inline M4 m4_mul(const M4& a, const M4& b) {
+    M4 m = m4_zero();
+    for (int r = 0; r < 4; ++r)
+        for (int c = 0; c < 4; ++c)
+            m.d[r][c] = a.d[r][0] * b.d[0][c] + a.d[r][1] * b.d[1][c] + a.d[r][2] * b.d[2][c] + a.d[r][3] * b.d[3][c];
+    return m;
+}
+// matrix.rs:88-134 (Gauss-Jordan); returns false for "Singular matrix"
+static inline bool m4_inverse(const M4& in, M4* out) {
+    M4 temp = in;
+    M4 res = m4_identity();
+    for (int col = 0; col < 4; ++col) {
+        if (temp.d[col][col] == 0.0f) {
+            int big = col;
+            for (int row = 0; row < 4; ++row)
+                if (std::fabs(temp.d[row][col]) > std::fabs(temp.d[big][col])) big = row;
+            if (big == col) return false;
+            for (int j = 0; j < 4; ++j) {
+                float t = temp.d[col][j]; temp.d[col][j] = temp.d[big][j]; temp.d[big][j] = t;
+                t = res.d[col][j]; res.d[col][j] = res.d[big][j]; res.d[big][j] = t;
+            }
+        }
+        for (int row = 0; row < 4; ++row) {
+            if (row != col) {
+                float coeff = temp.d[row][col] / temp.d[col][col];
+                if (coeff != 0.0f) {
+                    for (int j = 0; j < 4; ++j) {
+                        temp.d[row][j] -= coeff * temp.d[col][j];
+                        res.d[row][j] -= coeff * res.d[col][j];
+                    }
+                    temp.d[row][col] = 0.0f;
+                }
+            }
+        }
+    }
+    for (int row = 0; row < 4; ++row)
+        for (int col = 0; col < 4; ++col) res.d[row][col] /= temp.d[row][row];
+    *out = res;
+    return true;
+}
+// matrix.rs:154-163 (direction: no translation)
+static inline V3 m4_mul_vec(const M4& m, V3 v) {
+    return v3(m.d[0][0] * v.x + m.d[0][1] * v.y + m.d[0][2] * v.z,
+              m.d[1][0] * v.x + m.d[1][1] * v.y + m.d[1][2] * v.z,
+              m.d[2][0] * v.x + m.d[2][1] * v.y + m.d[2][2] * v.z);
+}
+// matrix.rs:165-183 (point: affine)
+static inline V3 m4_mul_point(const M4& m, V3 p) {
+    return v3(m.d[0][0] * p.x + m.d[0][1] * p.y + m.d[0][2] * p.z + m.d[0][3] * 1.0f,
+              m.d[1][0] * p.x + m.d[1][1] * p.y + m.d[1][2] * p.z + m.d[1][3] * 1.0f,
+              m.d[2][0] * p.x + m.d[2][1] * p.y + m.d[2][2] * p.z + m.d[2][3] * 1.0f);
+}
+// matrix.rs:185-190
+static inline Ray m4_mul_ray(const M4& m, const Ray& r) { return Ray{m4_mul_point(m, r.origin), m4_mul_vec(m, r.dir)}; }
+// transform.rs:33-39
+static inline M4 transform_matrix(V3 translate, V3 rotate, V3 scale) {
+    return m4_mul(m4_mul(m4_mul(m4_mul(m4_translation(translate), m4_rotation_x(rotate.x)), m4_rotation_y(rotate.y)),
+                         m4_rotation_z(rotate.z)),
+                  m4_scale(scale));
+}
+
+// ---------------------------------------------------------------------------
+// texture.rs
+// ---------------------------------------------------------------------------
+struct UV {
+    float u, v;
+};
+struct Scene;
+enum TexType { TEX_CONSTANT = 0, TEX_TEST = 1, TEX_CHECKER = 2, TEX_IMAGE = 3, TEX_NOISE = 4, TEX_TURBULENCE = 5 };
+struct Texture {
+    int type;
+    RGB color;            // Constant
+    float repeat;         // Checker
+    int odd, even;        // Checker (texture indices)
+    uint32_t w, h, ch;    // Image
+    std::vector<uint8_t> texels;
+    float scale;          // Noise / Turbulence
+    uint32_t depth;       // Turbulence
+    float omega;          // Turbulence
+};
+
+// ---------------------------------------------------------------------------
+// material.rs / volume.rs (Isotropic)
+// ---------------------------------------------------------------------------
+enum MatType { MAT_LAMBERT = 0, MAT_METAL = 1, MAT_DIELECTRIC = 2, MAT_DIFFUSE_LIGHT = 3, MAT_ISOTROPIC = 4 };
+struct Material {
+    int type;
+    int albedo;      // texture index (albedo / emission)
+    int bump;        // texture index or -1
+    float param;     // roughness (clamped) or refractive index
+};
+// material.rs:112,162,209,233 ; volume.rs:37
+static inline bool material_is_important(const Material& m) {
+    return m.type == MAT_METAL || m.type == MAT_DIELECTRIC || m.type == MAT_DIFFUSE_LIGHT;
+}
+
+// ---------------------------------------------------------------------------
+// aggregate.rs AABB
+// ---------------------------------------------------------------------------
+struct AABB {
+    V3 min, max;
+};
+static inline AABB aabb_empty() { return AABB{v3(0, 0, 0), v3(0, 0, 0)}; }                 // aggregate.rs:423-428
+static inline AABB aabb_union(const AABB& a, const AABB& b) { return AABB{vmin(a.min, b.min), vmax(a.max, b.max)}; }  // :430-435
+static inline AABB aabb_union_point(const AABB& a, V3 p) { return AABB{vmin(a.min, p), vmax(a.max, p)}; }             // :437-442
+static inline V3 aabb_center(const AABB& a) {                                              // :444-450
+    return v3(a.min.x * 0.5f + a.max.x * 0.5f, a.min.y * 0.5f + a.max.y * 0.5f, a.min.z * 0.5f + a.max.z * 0.5f);
+}
+static inline int aabb_largest_axis(const AABB& a) {                                       // :452-461
+    V3 d = a.max - a.min;
+    if (d.x > d.y && d.x > d.z) return 0;
+    if (d.y > d.z) return 1;
+    return 2;
+}
+static inline float aabb_surface_area(const AABB& a) {                                     // :463-469
+    V3 d = a.max - a.min;
+    return 2.0f * (d.x * d.y + d.x * d.z + d.y * d.z);
+}
+// aggregate.rs:491-503
+static inline void aabb_intersect_helper(const AABB& b, const Ray& r, float t_min, float t_max, int axis, float* o_min, float* o_max) {
+    float inverse_direction = 1.0f / axis_of(r.dir, axis);
+    float t0 = (axis_of(b.min, axis) - axis_of(r.origin, axis)) * inverse_direction;
+    float t1 = (axis_of(b.max, axis) - axis_of(r.origin, axis)) * inverse_direction;
+    if (inverse_direction < 0.0f) std::swap(t0, t1);
+    *o_min = t0 > t_min ? t0 : t_min;
+    *o_max = t1 < t_min ? t1 : t_max;
+}
+// aggregate.rs:471-489
+static inline bool aabb_intersect(const AABB& b, const Ray& r, float t_min, float t_max) {
+    float a, c;
+    aabb_intersect_helper(b, r, t_min, t_max, 0, &a, &c);
+    if (c <= a) return false;
+    aabb_intersect_helper(b, r, a, c, 1, &a, &c);
+    if (c <= a) return false;
+    aabb_intersect_helper(b, r, a, c, 2, &a, &c);
+    if (c <= a) return false;
+    return true;
+}
+// A conventional (complete) slab test, used only to count how many nodes an
+// implementation with a complete test needs to visit.  It never rejects a box
+// that the ray segment (t_min, t_max) truly overlaps: exits are widened by a few ulp.
+static inline bool aabb_intersect_tight(const AABB& b, const Ray& r, float t_min, float t_max) {
+    float lo = t_min, hi = t_max;
+    for (int axis = 0; axis < 3; ++axis) {
+        float inv = 1.0f / axis_of(r.dir, axis);
+        float t0 = (axis_of(b.min, axis) - axis_of(r.origin, axis)) * inv;
+        float t1 = (axis_of(b.max, axis) - axis_of(r.origin, axis)) * inv;
+        if (inv < 0.0f) std::swap(t0, t1);
+        lo = t0 > lo ? t0 : lo;
+        hi = t1 < hi ? t1 : hi;
+    }
+    if (lo >= t_max) return false;          // same as the reference: entry at/after the closest hit
+    float hi_pad = hi + std::fabs(hi) * 1.0e-5f;
+    float lo_pad = lo - std::fabs(lo) * 1.0e-5f;
+    return !(hi_pad < lo_pad);
+}
+
+// ---------------------------------------------------------------------------
+// shape.rs
+// ---------------------------------------------------------------------------
+struct HitProps {  // shape.rs:13-19
+    V3 p, n;
+    UV uv;
+    V3 pu, pv;
+};
+struct Mesh {  // shape.rs:168-173
+    std::vector<V3> vertices;
+    std::vector<UV> tex_coords;
+    bool cull;
+    int material;
+};
+enum ShapeType { SHAPE_SPHERE = 0, SHAPE_TRIANGLE = 1, SHAPE_MEDIUM = 2 };
+struct Shape {
+    int type;
+    // Sphere (shape.rs:32-46)
+    M4 l2w, w2l;
+    float radius;
+    // Triangle (shape.rs:213-223)
+    int mesh;
+    int v0, v1, v2;
+    int t0, t1, t2;  // -1 = None
+    V3 pu, pv;
+    // ConstantMedium (volume.rs:44-48)
+    int boundary;  // index into Scene::boundaries
+    float density;
+    // common
+    int material;
+    int id;  // index in scene order (-1 for a medium boundary)
+};
+
+struct Stats {
+    uint64_t rays = 0, nodes = 0, tri_tests = 0, sphere_tests = 0;
+};
+
+struct Camera {  // camera.rs:11-19
+    V3 origin, lower_left_corner, horizontal, vertical, u, v;
+    float lens_radius;
+};
+
+struct BvhNode {  // aggregate.rs:169-184
+    bool leaf;
+    AABB box;
+    int cut_axis;
+    size_t right_offset;
+    std::vector<int> shapes;  // leaf: shape indices, in order
+};
+
+struct Scene {
+    std::vector<Texture> textures;
+    std::vector<Material> materials;
+    std::vector<Mesh> meshes;
+    std::vector<Shape> shapes;      // scene order (scene.rs:125-128)
+    std::vector<Shape> boundaries;  // boundary shapes owned by media
+    std::vector<int> important;     // scene.rs:131-140
+    std::vector<BvhNode> bvh;
+    int aggregate = 1;              // 0 = List, 1 = BVH
+    Camera camera;
+    uint32_t res_x = 0, res_y = 0, samples = 0;
+    bool use_importance = true;
+    std::string error;
+};
+
+// texture.rs:61-179
+static RGB texture_value(const Scene& sc, int tex, UV uv, V3 p) {
+    const Texture& t = sc.textures[tex];
+    switch (t.type) {
+        case TEX_CONSTANT:  // :74-78
+            return t.color;
+        case TEX_TEST: {  // :81-93
+            float w = 1.0f - uv.u - uv.v;
+            return v3(uv.u, uv.v, w < 0.0f ? 0.0f : w);
+        }
+        case TEX_CHECKER: {  // :109-119
+            float sines = dm_sin(t.repeat * p.x) * dm_sin(t.repeat * p.y) * dm_sin(t.repeat * p.z);
+            return sines < 0.0f ? texture_value(sc, t.odd, uv, p) : texture_value(sc, t.even, uv, p);
+        }
+        case TEX_IMAGE: {  // :129-141
+            uint32_t i = f32_as_u32(uv.u * (float)t.w) % t.w;
+            uint32_t j = f32_as_u32((1.0f - uv.v) * (float)t.h) % t.h;
+            const uint8_t* px = &t.texels[((size_t)j * t.w + i) * t.ch];
+            uint8_t r = px[0], g = t.ch >= 3 ? px[1] : px[0], b = t.ch >= 3 ? px[2] : px[0];
+            RGB c = v3((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f);
+            return c * c;  // color.rs:41-43
+        }
+        case TEX_NOISE:  // :147-151
+            return v3(0.5f, 0.5f, 0.5f) * (1.0f + noise(p * t.scale));
+        case TEX_TURBULENCE:  // :174-179
+            return v3(1.0f, 1.0f, 1.0f) * turbulence(p * t.scale, t.depth, t.omega);
+    }
+    return v3(0, 0, 0);
+}
+// texture.rs:63-66
+static inline float texture_bump_value(const Scene& sc, int tex, UV uv, V3 p) {
+    RGB b = texture_value(sc, tex, uv, p);
+    return (b.x + b.y + b.z) / 3.0f;
+}
+
+// --- Sphere ---------------------------------------------------------------
+// shape.rs:65-85
+static inline bool sphere_hit(const Shape& s, const Ray& r, float t_min, float t_max, float* t_out) {
+    Ray lr = m4_mul_ray(s.w2l, r);
+    V3 towards_origin = lr.origin - v3(0, 0, 0);
+    float a = dot(lr.dir, lr.dir);
+    float b = 2.0f * dot(towards_origin, lr.dir);
+    float c = dot(towards_origin, towards_origin) - (s.radius * s.radius);
+    float discriminant = b * b - 4.0f * a * c;
+    if (discriminant > 0.0f) {
+        float t_hit = (-b - std::sqrt(discriminant)) / (2.0f * a);
+        if (t_hit >= t_max || t_hit <= t_min) t_hit = (-b + std::sqrt(discriminant)) / (2.0f * a);
+        if (t_hit < t_max && t_hit > t_min) {
+            *t_out = t_hit;
+            return true;
+        }
+    }
+    return false;
+}
+static inline float signum(float f) {  // f32::signum
+    if (f != f) return f;
+    return std::signbit(f) ? -1.0f : 1.0f;
+}
+// shape.rs:87-123
+static inline HitProps sphere_hit_properties(const Shape& s, const Ray& r, float t_hit) {
+    const float one_over_2pi = 1.0f / (2.0f * kPi);  // shape.rs:63
+    Ray lr = m4_mul_ray(s.w2l, r);
+    V3 hp = point_at(lr, t_hit);
+    hp = hp * (std::fabs(s.radius) / length(hp - v3(0, 0, 0)));
+    float theta = dm_asin(clampf(hp.y / s.radius, -1.0f, 1.0f));
+    float inverse_y_radius = (signum(s.radius) * 1.0f) / std::sqrt(hp.x * hp.x + hp.z * hp.z);
+    V3 pu = v3(2.0f * kPi * hp.z, 0.0f, -2.0f * kPi * hp.x);
+    V3 pv = (-kPi) * v3(hp.y * hp.x * inverse_y_radius, (-s.radius) * dm_cos(theta), hp.y * hp.z * inverse_y_radius);
+    HitProps h;
+    h.p = point_at(r, t_hit);
+    h.n = normalized(m4_mul_vec(s.l2w, (point_at(lr, t_hit) - v3(0, 0, 0)) / s.radius));
+    h.uv.u = 1.0f - ((dm_atan2(hp.z, hp.x) + kPi) * one_over_2pi);
+    h.uv.v = (theta + kFracPi2) * kFrac1Pi;
+    h.pu = m4_mul_vec(s.l2w, pu);
+    h.pv = m4_mul_vec(s.l2w, pv);
+    return h;
+}
+// shape.rs:129-139
+static inline AABB sphere_bbox(const Shape& s) {
+    V3 c = m4_mul_point(s.l2w, v3(0, 0, 0));
+    V3 lo = c - v3(s.radius, s.radius, s.radius);
+    V3 hi = c + v3(s.radius, s.radius, s.radius);
+    return AABB{vmin(lo, hi), vmax(lo, hi)};
+}
+// shape.rs:141-157
+static inline float sphere_pdf(const Shape& s, const Ray& r) {
+    float t;
+    if (!sphere_hit(s, r, kTMin, kTMax, &t)) return 0.0f;
+    Ray lr = m4_mul_ray(s.w2l, r);
+    float cos_theta_max = std::sqrt(float_max(1.0f - s.radius * s.radius / sqlen(v3(0, 0, 0) - lr.origin), 0.0f));
+    float solid_angle = 2.0f * kPi * (1.0f - cos_theta_max);
+    return 1.0f / solid_angle;
+}
+// shape.rs:159-165
+static inline V3 sphere_random_dir_towards(const Shape& s, V3 from_origin, Rng& g) {
+    V3 local_point = m4_mul_point(s.w2l, from_origin);
+    V3 dir = v3(0, 0, 0) - local_point;
+    ONB o = onb_new(dir);
+    V3 d = random_to_sphere(g, s.radius, sqlen(dir));
+    return m4_mul_vec(s.l2w, onb_local(o, d));
+}
+
+// --- Triangle ---------------------------------------------------------------
+// shape.rs:190-210
+static inline void mesh_get_uvs(const Mesh& m, int t0, int t1, int t2, UV* uv0, UV* uv1, UV* uv2) {
+    *uv0 = t0 >= 0 ? m.tex_coords[t0] : UV{0.0f, 0.0f};
+    *uv1 = t1 >= 0 ? m.tex_coords[t1] : UV{1.0f, 0.0f};
+    *uv2 = t2 >= 0 ? m.tex_coords[t2] : UV{1.0f, 1.0f};
+}
+// shape.rs:225-328 ; returns "" on success or the error text
+static std::string triangle_new(const Scene& sc, Shape* tri) {
+    const Mesh& mesh = sc.meshes[tri->mesh];
+    size_t nv = mesh.vertices.size();
+    char buf[512];
+    if (nv == 0 || nv - 1 < (size_t)tri->v0 || nv - 1 < (size_t)tri->v1 || nv - 1 < (size_t)tri->v2) {
+        std::snprintf(buf, sizeof buf, "Triangle mesh has length %zu but attempted to make a Triangle with indices %d, %d, %d.", nv,
+                      tri->v0, tri->v1, tri->v2);
+        return buf;
+    }
+    int ts[3] = {tri->t0, tri->t1, tri->t2};
+    for (int k = 0; k < 3; ++k) {
+        if (ts[k] >= 0 && (size_t)ts[k] >= mesh.tex_coords.size()) {
+            std::snprintf(buf, sizeof buf,
+                          "Triangle texture coordinates have length %zu but attempted to make a Triangle with texture index %d.",
+                          mesh.tex_coords.size(), ts[k]);
+            return buf;
+        }
+    }
+    V3 vertex0 = mesh.vertices[tri->v0], vertex1 = mesh.vertices[tri->v1], vertex2 = mesh.vertices[tri->v2];
+    UV uv0, uv1, uv2;
+    mesh_get_uvs(mesh, tri->t0, tri->t1, tri->t2, &uv0, &uv1, &uv2);
+    V3 pu = v3(0, 0, 0), pv = v3(0, 0, 0);
+    UV duv02 = UV{uv0.u - uv2.u, uv0.v - uv2.v};
+    UV duv12 = UV{uv1.u - uv2.u, uv1.v - uv2.v};
+    V3 dp02 = vertex0 - vertex2;
+    V3 dp12 = vertex1 - vertex2;
+    float uv_determinant = duv02.u * duv12.v - duv02.v * duv12.u;
+    bool degenerate_uv = std::fabs(uv_determinant) < kEps;
+    if (!degenerate_uv) {
+        float inv_det = 1.0f / uv_determinant;
+        pu = (duv12.v * dp02 - duv02.v * dp12) * inv_det;
+        pv = (-duv12.u * dp02 + duv02.u * dp12) * inv_det;
+    }
+    if (degenerate_uv || sqlen(cross(pu, pv)) == 0.0f) {
+        V3 ng = cross(vertex2 - vertex0, vertex1 - vertex0);
+        if (sqlen(ng) == 0.0f) {
+            std::snprintf(buf, sizeof buf, "Triangle texture coordinates are degenerate. UV1: (%g, %g), UV2: (%g, %g), UV3: (%g, %g)",
+                          uv0.u, uv0.v, uv1.u, uv1.v, uv2.u, uv2.v);
+            return buf;
+        }
+        ng = normalized(ng);
+        if (std::fabs(ng.x) > std::fabs(ng.y)) {
+            pu = v3(-ng.z, 0.0f, ng.x) / std::sqrt(ng.x * ng.x + ng.z * ng.z);
+        } else {
+            pu = v3(0.0f, ng.z, -ng.y) / std::sqrt(ng.y * ng.y + ng.z * ng.z);
+        }
+        pv = cross(ng, pu);
+    }
+    tri->pu = pu;
+    tri->pv = pv;
+    return "";
+}
+// shape.rs:335-372
+static inline bool triangle_hit(const Scene& sc, const Shape& s, const Ray& r, float t_min, float t_max, float* t_out) {
+    const Mesh& m = sc.meshes[s.mesh];
+    V3 vertex0 = m.vertices[s.v0], vertex1 = m.vertices[s.v1], vertex2 = m.vertices[s.v2];
+    V3 edge_1 = vertex1 - vertex0;
+    V3 edge_2 = vertex2 - vertex0;
+    V3 p_vec = cross(r.dir, edge_2);
+    float determinant = dot(edge_1, p_vec);
+    if (!m.cull && determinant > -kEps && determinant < kEps) {
+        return false;
+    } else if (m.cull && determinant < kEps) {
+        return false;
+    }
+    float inverse_determinant = 1.0f / determinant;
+    V3 t_vec = r.origin - vertex0;
+    float u = dot(t_vec, p_vec) * inverse_determinant;
+    if (u < 0.0f || u > 1.0f) return false;
+    V3 q_vec = cross(t_vec, edge_1);
+    float v = dot(r.dir, q_vec) * inverse_determinant;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t_hit = dot(edge_2, q_vec) * inverse_determinant;
+    if (t_hit < t_max && t_hit > t_min) {
+        *t_out = t_hit;
+        return true;
+    }
+    return false;
+}
+// shape.rs:374-424
+static inline HitProps triangle_hit_properties(const Scene& sc, const Shape& s, const Ray& r, float t_hit) {
+    const Mesh& m = sc.meshes[s.mesh];
+    V3 vertex0 = m.vertices[s.v0], vertex1 = m.vertices[s.v1], vertex2 = m.vertices[s.v2];
+    V3 edge_1 = vertex1 - vertex0;
+    V3 edge_2 = vertex2 - vertex0;
+    V3 p_vec = cross(r.dir, edge_2);
+    float determinant = dot(edge_1, p_vec);
+    V3 normal = normalized(cross(edge_1, edge_2));
+    if (determinant < 0.0f) normal = -normal;
+    float inverse_determinant = 1.0f / determinant;
+    V3 t_vec = r.origin - vertex0;
+    float u = dot(t_vec, p_vec) * inverse_determinant;
+    V3 q_vec = cross(t_vec, edge_1);
+    float v = dot(r.dir, q_vec) * inverse_determinant;
+    float w = 1.0f - u - v;
+    UV uv0, uv1, uv2;
+    mesh_get_uvs(m, s.t0, s.t1, s.t2, &uv0, &uv1, &uv2);
+    HitProps h;
+    h.uv.u = uv0.u * u + uv1.u * v + uv2.u * w;
+    h.uv.v = uv0.v * u + uv1.v * v + uv2.v * w;
+    V3 pu = s.pu;
+    if (determinant < 0.0f) pu = -pu;
+    h.p = point_at(r, t_hit);
+    h.n = normal;
+    h.pu = pu;
+    h.pv = s.pv;
+    return h;
+}
+// shape.rs:430-439
+static inline AABB triangle_bbox(const Scene& sc, const Shape& s) {
+    const Mesh& m = sc.meshes[s.mesh];
+    V3 a = m.vertices[s.v0], b = m.vertices[s.v1], c = m.vertices[s.v2];
+    return AABB{vmin(a, vmin(b, c)), vmax(a, vmax(b, c))};
+}
+// shape.rs:441-458
+static inline float triangle_pdf(const Scene& sc, const Shape& s, const Ray& r) {
+    const Mesh& m = sc.meshes[s.mesh];
+    V3 vertex0 = m.vertices[s.v0], vertex1 = m.vertices[s.v1], vertex2 = m.vertices[s.v2];
+    float t_hit;
+    if (!triangle_hit(sc, s, r, kTMin, kTMax, &t_hit)) return 0.0f;
+    HitProps hp = triangle_hit_properties(sc, s, r, t_hit);
+    float area = 0.5f * length(cross(vertex1 - vertex0, vertex2 - vertex0));
+    float dist_squared = t_hit * t_hit * sqlen(r.dir);
+    float cosine = std::fabs(dot(r.dir, hp.n) / length(r.dir));
+    return dist_squared / (cosine * area);
+}
+// shape.rs:460-471
+static inline V3 triangle_random_dir_towards(const Scene& sc, const Shape& s, V3 from_origin, Rng& g) {
+    const Mesh& m = sc.meshes[s.mesh];
+    V3 vertex0 = m.vertices[s.v0], vertex1 = m.vertices[s.v1], vertex2 = m.vertices[s.v2];
+    float r1 = rng_f32(g);
+    float r2 = rng_f32(g);
+    V3 random_point = vertex0 * (1.0f - std::sqrt(r1)) + vertex1 * (std::sqrt(r1) * (1.0f - r2)) + vertex2 * (r2 * std::sqrt(r1));
+    return random_point - from_origin;
+}
+
+// --- Shape dispatch (trait Shape, shape.rs:21-29) and ConstantMedium ---------
+struct HitCtx {  // what a stochastic primitive needs to make its keyed draw
+    const Rng* rng;
+    uint32_t depth;
+    Stats* stats;
+};
+static bool shape_hit(const Scene& sc, const Shape& s, const Ray& r, float t_min, float t_max, const HitCtx& cx, float* t_out);
+// volume.rs:65-102
+static bool medium_hit(const Scene& sc, const Shape& s, const Ray& r, float t_min, float t_max, const HitCtx& cx, float* t_out) {
+    const Shape& b = sc.boundaries[s.boundary];
+    float t_hit1, t_hit2;
+    if (!shape_hit(sc, b, r, -kTMax, kTMax, cx, &t_hit1)) return false;
+    if (!shape_hit(sc, b, r, t_hit1 + kEps, kTMax, cx, &t_hit2)) return false;
+    if (t_hit1 < t_min) t_hit1 = t_min;
+    if (t_hit2 > t_max) t_hit2 = t_max;
+    if (t_hit1 >= t_hit2) return false;
+    if (t_hit1 < 0.0f) t_hit1 = 0.0f;
+    float distance_inside_boundary = (t_hit2 - t_hit1) * length(r.dir);
+    float xi = rng_keyed_f32(*cx.rng, cx.depth, (uint32_t)s.id);
+    float hit_dist = (-1.0f / s.density) * dm_log(xi);
+    if (hit_dist > distance_inside_boundary) return false;
+    *t_out = t_hit1 + (hit_dist / length(r.dir));
+    return true;
+}
+static bool shape_hit(const Scene& sc, const Shape& s, const Ray& r, float t_min, float t_max, const HitCtx& cx, float* t_out) {
+    switch (s.type) {
+        case SHAPE_SPHERE:
+            if (cx.stats) cx.stats->sphere_tests++;
+            return sphere_hit(s, r, t_min, t_max, t_out);
+        case SHAPE_TRIANGLE:
+            if (cx.stats) cx.stats->tri_tests++;
+            return triangle_hit(sc, s, r, t_min, t_max, t_out);
+        default:
+            return medium_hit(sc, s, r, t_min, t_max, cx, t_out);
+    }
+}
+static HitProps shape_hit_properties(const Scene& sc, const Shape& s, const Ray& r, float t) {
+    switch (s.type) {
+        case SHAPE_SPHERE: return sphere_hit_properties(s, r, t);
+        case SHAPE_TRIANGLE: return triangle_hit_properties(sc, s, r, t);
+        default: return shape_hit_properties(sc, sc.boundaries[s.boundary], r, t);  // volume.rs:104-106
+    }
+}
+static AABB shape_bbox(const Scene& sc, const Shape& s) {
+    switch (s.type) {
+        case SHAPE_SPHERE: return sphere_bbox(s);
+        case SHAPE_TRIANGLE: return triangle_bbox(sc, s);
+        default: return shape_bbox(sc, sc.boundaries[s.boundary]);  // volume.rs:112-114
+    }
+}
+static float shape_pdf(const Scene& sc, const Shape& s, const Ray& r) {
+    switch (s.type) {
+        case SHAPE_SPHERE: return sphere_pdf(s, r);
+        case SHAPE_TRIANGLE: return triangle_pdf(sc, s, r);
+        default: return shape_pdf(sc, sc.boundaries[s.boundary], r);  // volume.rs:116-118
+    }
+}
+static V3 shape_random_dir_towards(const Scene& sc, const Shape& s, V3 from, Rng& g) {
+    switch (s.type) {
+        case SHAPE_SPHERE: return sphere_random_dir_towards(s, from, g);
+        case SHAPE_TRIANGLE: return triangle_random_dir_towards(sc, s, from, g);
+        default: return shape_random_dir_towards(sc, sc.boundaries[s.boundary], from, g);  // volume.rs:120-122
+    }
+}
+
+// ---------------------------------------------------------------------------
+// aggregate.rs : List, BVH build, BVH traversal
+// ---------------------------------------------------------------------------
+// aggregate.rs:144-165
+static bool list_hit(const Scene& sc, const std::vector<int>& list, const Ray& r, float t_min, float t_max, const HitCtx& cx, int* shape_out,
+                     float* t_out) {
+    float modified_t_max = t_max;
+    int hit_shape = -1;
+    for (int idx : list) {
+        float t;
+        if (shape_hit(sc, sc.shapes[idx], r, t_min, modified_t_max, cx, &t)) {
+            modified_t_max = t;
+            hit_shape = idx;
+        }
+    }
+    if (hit_shape >= 0) {
+        *shape_out = hit_shape;
+        *t_out = modified_t_max;
+        return true;
+    }
+    return false;
+}
+// aggregate.rs:193-322
+static void new_bvh_helper(const Scene& sc, std::vector<BvhNode>& bvh, std::vector<int> shapes) {
+    AABB total_bounds = aabb_empty();
+    for (int s : shapes) total_bounds = aabb_union(total_bounds, shape_bbox(sc, sc.shapes[s]));
+    if (shapes.size() <= 2) {
+        bvh.push_back(BvhNode{true, total_bounds, 0, 0, shapes});
+        return;
+    }
+    AABB centroid_bounds = aabb_empty();
+    for (int s : shapes) centroid_bounds = aabb_union_point(centroid_bounds, aabb_center(shape_bbox(sc, sc.shapes[s])));
+    int cut_axis = aabb_largest_axis(centroid_bounds);
+    if (axis_of(centroid_bounds.max, cut_axis) == axis_of(centroid_bounds.min, cut_axis)) {
+        bvh.push_back(BvhNode{true, total_bounds, 0, 0, shapes});
+        return;
+    }
+    // slice::sort_by is a stable sort
+    std::stable_sort(shapes.begin(), shapes.end(), [&](int a, int b) {
+        float a_c = axis_of(aabb_center(shape_bbox(sc, sc.shapes[a])), cut_axis);
+        float b_c = axis_of(aabb_center(shape_bbox(sc, sc.shapes[b])), cut_axis);
+        return a_c < b_c;
+    });
+    size_t n = shapes.size();
+    std::vector<AABB> reverse_bounds(n, aabb_empty());
+    // (0..n-1).rev(): index n-1 is never written and keeps the origin point box
+    for (size_t k = n - 1; k-- > 0;) {
+        reverse_bounds[k] = shape_bbox(sc, sc.shapes[shapes[k]]);
+        if (k + 1 < n) reverse_bounds[k] = aabb_union(reverse_bounds[k], reverse_bounds[k + 1]);
+    }
+    AABB forward_bounds = aabb_empty();
+    float min_cost = kTMax;
+    size_t min_cost_index = 0;
+    for (size_t idx = 0; idx < n - 1; ++idx) {
+        forward_bounds = aabb_union(forward_bounds, shape_bbox(sc, sc.shapes[shapes[idx]]));
+        float cost = 1.0f + ((aabb_surface_area(forward_bounds) / aabb_surface_area(total_bounds)) * (float)(idx + 1)) +
+                     ((aabb_surface_area(reverse_bounds[idx + 1]) / aabb_surface_area(total_bounds)) * (float)(n - (idx + 1)));
+        if (cost < min_cost) {
+            min_cost = cost;
+            min_cost_index = idx;
+        }
+    }
+    if (min_cost < (float)n) {
+        std::vector<int> second_half(shapes.begin() + (min_cost_index + 1), shapes.end());
+        shapes.resize(min_cost_index + 1);
+        bvh.push_back(BvhNode{false, aabb_empty(), cut_axis, 0, {}});
+        size_t node_idx = bvh.size() - 1;
+        new_bvh_helper(sc, bvh, shapes);
+        bvh[node_idx].box = total_bounds;
+        bvh[node_idx].right_offset = bvh.size() - node_idx;
+        new_bvh_helper(sc, bvh, second_half);
+        return;
+    }
+    bvh.push_back(BvhNode{true, total_bounds, 0, 0, shapes});
+}
+// aggregate.rs:324-401 ; aabb_mode 0 = the reference's test, 1 = complete slab test (node counting only)
+static bool bvh_hit(const Scene& sc, const Ray& r, float t_min, float t_max, std::vector<size_t>& to_explore, int aabb_mode, const HitCtx& cx,
+                    int* shape_out, float* t_out) {
+    const std::vector<BvhNode>& bvh = sc.bvh;
+    if (bvh.empty()) return false;
+    float modified_t_max = t_max;
+    int hit_shape = -1;
+    size_t to_explore_count = 1;
+    to_explore[0] = 0;
+    while (to_explore_count > 0) {
+        to_explore_count -= 1;
+        size_t cur_idx = to_explore[to_explore_count];
+        const BvhNode& node = bvh[cur_idx];
+        if (cx.stats) cx.stats->nodes++;
+        bool inside = aabb_mode == 0 ? aabb_intersect(node.box, r, t_min, modified_t_max) : aabb_intersect_tight(node.box, r, t_min, modified_t_max);
+        if (!inside) continue;
+        if (node.leaf) {
+            int s;
+            float t;
+            if (list_hit(sc, node.shapes, r, t_min, modified_t_max, cx, &s, &t)) {
+                modified_t_max = t;
+                hit_shape = s;
+            }
+        } else {
+            if (axis_of(r.dir, node.cut_axis) < 0.0f) {
+                to_explore[to_explore_count++] = cur_idx + node.right_offset;
+                to_explore[to_explore_count++] = cur_idx + 1;
+            } else {
+                to_explore[to_explore_count++] = cur_idx + 1;
+                to_explore[to_explore_count++] = cur_idx + node.right_offset;
+            }
+        }
+    }
+    if (hit_shape >= 0) {
+        *shape_out = hit_shape;
+        *t_out = modified_t_max;
+        return true;
+    }
+    return false;
+}
+
+struct Workspace {  // aggregate.rs:109-112, 405-409
+    std::vector<size_t> to_explore;
+    std::vector<int> all;  // List aggregate: every shape in scene order
+};
+static Workspace get_workspace(const Scene& sc) {
+    Workspace w;
+    w.to_explore.assign(std::max<size_t>(sc.bvh.size(), 1), 0);
+    if (sc.aggregate == 0) {
+        w.all.resize(sc.shapes.size());
+        for (size_t i = 0; i < sc.shapes.size(); ++i) w.all[i] = (int)i;
+    }
+    return w;
+}
+// aggregate.rs:133-139 + trait dispatch
+static bool aggregate_hit(const Scene& sc, Workspace& ws, const Ray& r, float t_min, float t_max, int aabb_mode, const HitCtx& cx, int* shape_out,
+                          float* t_out) {
+    if (sc.aggregate == 0) return list_hit(sc, ws.all, r, t_min, t_max, cx, shape_out, t_out);
+    return bvh_hit(sc, r, t_min, t_max, ws.to_explore, aabb_mode, cx, shape_out, t_out);
+}
+
+// ---------------------------------------------------------------------------
+// pdf.rs
+// ---------------------------------------------------------------------------
+// pdf.rs:51-58
+static inline float cosine_pdf_value(V3 normal, const Ray& r) {
+    float cosine = dot(normalized(r.dir), normal);
+    return cosine < 0.0f ? 0.0f : cosine / kPi;
+}
+// pdf.rs:60-62
+static inline V3 cosine_pdf_generate(V3 normal, Rng& g) {
+    ONB o = onb_new(normal);
+    V3 d = random_cosine_direction(g);
+    return onb_local(o, d);
+}
+// pdf.rs:98-107 (Mixture of PDF::Shape members)
+static inline float important_value(const Scene& sc, const Ray& r) {
+    float weight = 1.0f / (float)sc.important.size();
+    float sum = 0.0f;
+    for (int s : sc.important) sum += weight * shape_pdf(sc, sc.shapes[s], r);
+    return sum;
+}
+// pdf.rs:109-114
+static inline V3 important_generate(const Scene& sc, V3 origin, Rng& g) {
+    uint32_t k = rng_index(g, (uint32_t)sc.important.size());
+    return shape_random_dir_towards(sc, sc.shapes[sc.important[k]], origin, g);
+}
+
+// ---------------------------------------------------------------------------
+// material.rs
+// ---------------------------------------------------------------------------
+static inline V3 reflect(V3 v, V3 n) { return v - 2.0f * dot(v, n) * n; }  // :15-17
+static inline V3 refract(V3 v, V3 n, float refracted_index) {            // :19-24
+    float cos_theta = dot(-v, n);
+    V3 r_out_parallel = refracted_index * (v + cos_theta * n);
+    V3 r_out_perp = (-std::sqrt(1.0f - sqlen(r_out_parallel))) * n;
+    return r_out_parallel + r_out_perp;
+}
+static inline float powi5(float a) {  // f32::powi(5): square-and-multiply, a * ((a*a)*(a*a))
+    float a2 = a * a;
+    float a4 = a2 * a2;
+    return a * a4;
+}
+static inline float schlick(float cosine, float index) {  // :26-30
+    float r0 = (1.0f - index) / (1.0f + index);
+    r0 = r0 * r0;
+    return r0 + (1.0f - r0) * powi5(1.0f - cosine);
+}
+// material.rs:33-54
+static inline V3 bump_modify(const Scene& sc, const HitProps& hp, int bump_tex) {
+    const float BUMP_DELTA = 0.005f;
+    float displacement = texture_bump_value(sc, bump_tex, hp.uv, hp.p);
+    float displacement_u = texture_bump_value(sc, bump_tex, UV{hp.uv.u + BUMP_DELTA, hp.uv.v}, hp.p + BUMP_DELTA * hp.pu);
+    float displacement_v = texture_bump_value(sc, bump_tex, UV{hp.uv.u, hp.uv.v + BUMP_DELTA}, hp.p + BUMP_DELTA * hp.pv);
+    V3 new_pu = hp.pu + ((displacement_u - displacement) / BUMP_DELTA) * hp.n;
+    V3 new_pv = hp.pv + ((displacement_v - displacement) / BUMP_DELTA) * hp.n;
+    return normalized(cross(new_pu, new_pv));
+}
+struct Scatter {
+    bool scattered;   // false = None
+    bool specular;    // Reflectance::Specular vs Reflectance::PDF(Cosine)
+    Ray spec_ray;
+    V3 pdf_normal;    // pdf::Cosine::new(normal)
+    RGB attenuation;
+};
+// material.rs:98-110 (Lambert), :145-160 (Metal), :172-207 (Dielectric), :224-227 (DiffuseLight), volume.rs:27-35 (Isotropic)
+static Scatter material_scatter(const Scene& sc, const Material& m, const Ray& in_ray, const HitProps& hp, Rng& g) {
+    Scatter s;
+    s.scattered = true;
+    s.specular = false;
+    s.spec_ray = Ray{v3(0, 0, 0), v3(0, 0, 0)};
+    s.pdf_normal = v3(0, 0, 0);
+    s.attenuation = v3(0, 0, 0);
+    switch (m.type) {
+        case MAT_LAMBERT: {
+            V3 n = m.bump < 0 ? hp.n : bump_modify(sc, hp, m.bump);
+            s.pdf_normal = n;
+            s.attenuation = texture_value(sc, m.albedo, hp.uv, hp.p);
+            return s;
+        }
+        case MAT_METAL: {
+            V3 n = m.bump < 0 ? hp.n : bump_modify(sc, hp, m.bump);
+            V3 reflected = reflect(normalized(in_ray.dir), n);
+            V3 out_ray_dir = reflected + m.param * unit_sphere_random(g);
+            s.specular = true;
+            s.spec_ray = Ray{hp.p, out_ray_dir};
+            s.attenuation = texture_value(sc, m.albedo, hp.uv, hp.p);
+            return s;
+        }
+        case MAT_DIELECTRIC: {
+            s.specular = true;
+            s.attenuation = v3(1.0f, 1.0f, 1.0f);
+            float etai_over_etat;
+            V3 normal_for_use;
+            if (dot(in_ray.dir, hp.n) < 0.0f) {
+                etai_over_etat = 1.0f / m.param;
+                normal_for_use = hp.n;
+            } else {
+                etai_over_etat = m.param;
+                normal_for_use = -hp.n;
+            }
+            V3 unit_direction = normalized(in_ray.dir);
+            float cos_theta = float_min(dot(-unit_direction, normal_for_use), 1.0f);
+            float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
+            if (etai_over_etat * sin_theta > 1.0f) {
+                s.spec_ray = Ray{hp.p, reflect(unit_direction, normal_for_use)};
+                return s;
+            }
+            float reflect_prob = schlick(cos_theta, etai_over_etat);
+            if (rng_f32(g) < reflect_prob) {
+                s.spec_ray = Ray{hp.p, reflect(unit_direction, normal_for_use)};
+                return s;
+            }
+            s.spec_ray = Ray{hp.p, refract(unit_direction, normal_for_use, etai_over_etat)};
+            return s;
+        }
+        case MAT_DIFFUSE_LIGHT:
+            s.scattered = false;
+            return s;
+        case MAT_ISOTROPIC: {
+            s.specular = true;
+            s.spec_ray = Ray{hp.p, unit_sphere_random(g)};
+            s.attenuation = texture_value(sc, m.albedo, hp.uv, hp.p);
+            return s;
+        }
+    }
+    s.scattered = false;
+    return s;
+}
+// material.rs:72-74, 229-231
+static inline bool material_emit(const Scene& sc, const Material& m, const HitProps& hp, RGB* e) {
+    if (m.type != MAT_DIFFUSE_LIGHT) return false;
+    *e = texture_value(sc, m.albedo, hp.uv, hp.p);
+    return true;
+}
+
+// ---------------------------------------------------------------------------
+// camera.rs
+// ---------------------------------------------------------------------------
+// camera.rs:22-51
+static Camera camera_new(V3 pos, V3 look_at, V3 up, float vertical_fov, float aspect, float aperture, float focus_dist) {
+    float theta = to_radians(vertical_fov);
+    float half_height = std::tan(theta / 2.0f);
+    float half_width = aspect * half_height;
+    V3 w = normalized(pos - look_at);
+    V3 u = normalized(cross(up, w));
+    V3 v = cross(w, u);
+    Camera c;
+    c.origin = pos;
+    c.lower_left_corner = pos - (half_width * focus_dist * u) - (half_height * focus_dist * v) - (w * focus_dist);
+    c.horizontal = 2.0f * half_width * focus_dist * u;
+    c.vertical = 2.0f * half_height * focus_dist * v;
+    c.u = u;
+    c.v = v;
+    c.lens_radius = aperture / 2.0f;
+    return c;
+}
+// camera.rs:53-63
+static inline Ray camera_get_ray(const Camera& c, float s, float t, Rng& g) {
+    V3 ray_disk = c.lens_radius * random_unit_disk(g);
+    V3 offset = c.u * ray_disk.x + c.v * ray_disk.y;
+    return Ray{c.origin + offset, c.lower_left_corner + (c.horizontal * s) + (c.vertical * t) - c.origin - offset};
+}
+
+// ---------------------------------------------------------------------------
+// main.rs backgrounds
+// ---------------------------------------------------------------------------
+static inline RGB background(int bg, const Ray& r) {
+    if (bg == 0) return v3(0, 0, 0);  // main.rs:268-270
+    // main.rs:259-267 (commented-out sky blend)
+    V3 dir_normal = normalized(r.dir);
+    float t = 0.5f * (dir_normal.y + 1.0f);
+    return v3(1.0f, 1.0f, 1.0f) * (1.0f - t) + v3(0.5f, 0.7f, 1.0f) * t;
+}
+
+// ---------------------------------------------------------------------------
+// aggregate.rs:16-105  trace
+// ---------------------------------------------------------------------------
+static const int kMaxDepth = 50;  // aggregate.rs:14
+struct TraceCfg {
+    int bg;
+    int aabb_mode;
+    int max_depth;
+};
+// Faithful recursive form.
+static RGB trace_recursive(const Scene& sc, const Ray& r, Workspace& ws, Rng& g, const TraceCfg& cfg, Stats& st, int depth) {
+    HitCtx cx{&g, (uint32_t)depth, &st};
+    int shape;
+    float t;
+    st.rays++;
+    bool hit = aggregate_hit(sc, ws, r, kTMin, kTMax, cfg.aabb_mode, cx, &shape, &t);
+    if (depth < cfg.max_depth && hit) {
+        const Shape& s = sc.shapes[shape];
+        HitProps hp = shape_hit_properties(sc, s, r, t);
+        hp.uv.u = clampf(hp.uv.u, 0.0f, 1.0f);
+        hp.uv.v = clampf(hp.uv.v, 0.0f, 1.0f);
+        const Material& m = sc.materials[s.material];
+        RGB e;
+        if (material_emit(sc, m, hp, &e)) return e;
+        Scatter sp = material_scatter(sc, m, r, hp, g);
+        if (!sp.scattered) return v3(0, 0, 0);
+        if (sp.specular) return sp.attenuation * trace_recursive(sc, sp.spec_ray, ws, g, cfg, st, depth + 1);
+        Ray scattered;
+        float pdf_val;
+        if (!sc.important.empty()) {
+            // pdf.rs:121-128 then :117-119
+            float xi = rng_f32(g);
+            V3 d = xi < 0.5f ? important_generate(sc, hp.p, g) : cosine_pdf_generate(sp.pdf_normal, g);
+            scattered = Ray{hp.p, d};
+            pdf_val = important_value(sc, scattered) * 0.5f + cosine_pdf_value(sp.pdf_normal, scattered) * 0.5f;
+        } else {
+            scattered = Ray{hp.p, cosine_pdf_generate(sp.pdf_normal, g)};
+            pdf_val = cosine_pdf_value(sp.pdf_normal, scattered);
+        }
+        return sp.attenuation * cosine_pdf_value(sp.pdf_normal, scattered) * trace_recursive(sc, scattered, ws, g, cfg, st, depth + 1) / pdf_val;
+    }
+    return background(cfg.bg, r);
+}
+// Loop form of the same estimator: throughput is multiplied down the path instead
+// of radiance being multiplied up the recursion.  Same draws, same decisions; only
+// the f32 rounding order of the final product differs.
+static RGB trace_iterative(const Scene& sc, const Ray& r0, Workspace& ws, Rng& g, const TraceCfg& cfg, Stats& st) {
+    Ray r = r0;
+    RGB thr = v3(1.0f, 1.0f, 1.0f);
+    for (int depth = 0;; ++depth) {
+        HitCtx cx{&g, (uint32_t)depth, &st};
+        int shape;
+        float t;
+        st.rays++;
+        bool hit = aggregate_hit(sc, ws, r, kTMin, kTMax, cfg.aabb_mode, cx, &shape, &t);
+        if (!(depth < cfg.max_depth && hit)) return thr * background(cfg.bg, r);
+        const Shape& s = sc.shapes[shape];
+        HitProps hp = shape_hit_properties(sc, s, r, t);
+        hp.uv.u = clampf(hp.uv.u, 0.0f, 1.0f);
+        hp.uv.v = clampf(hp.uv.v, 0.0f, 1.0f);
+        const Material& m = sc.materials[s.material];
+        RGB e;
+        if (material_emit(sc, m, hp, &e)) return thr * e;
+        Scatter sp = material_scatter(sc, m, r, hp, g);
+        if (!sp.scattered) return thr * v3(0, 0, 0);
+        if (sp.specular) {
+            thr = thr * sp.attenuation;
+            r = sp.spec_ray;
+            continue;
+        }
+        Ray scattered;
+        float pdf_val;
+        if (!sc.important.empty()) {
+            float xi = rng_f32(g);
+            V3 d = xi < 0.5f ? important_generate(sc, hp.p, g) : cosine_pdf_generate(sp.pdf_normal, g);
+            scattered = Ray{hp.p, d};
+            pdf_val = important_value(sc, scattered) * 0.5f + cosine_pdf_value(sp.pdf_normal, scattered) * 0.5f;
+        } else {
+            scattered = Ray{hp.p, cosine_pdf_generate(sp.pdf_normal, g)};
+            pdf_val = cosine_pdf_value(sp.pdf_normal, scattered);
+        }
+        thr = (thr * (sp.attenuation * cosine_pdf_value(sp.pdf_normal, scattered))) / pdf_val;
+        r = scattered;
+    }
+}
+
+}  // namespace orc
+
+// ===========================================================================
+// C API (ctypes)
+// ===========================================================================
+using namespace orc;
+
+extern "C" {
+
+void* orc_scene_new() { return new Scene(); }
+void orc_scene_free(void* s) { delete (Scene*)s; }
+const char* orc_scene_error(void* s) { return ((Scene*)s)->error.c_str(); }
+
+// texture.rs constructors (scene.rs:189-261)
+int orc_add_texture_constant(void* s, float r, float g, float b) {
+    Texture t{}; t.type = TEX_CONSTANT; t.color = v3(r, g, b);
+    ((Scene*)s)->textures.push_back(t);
+    return (int)((Scene*)s)->textures.size() - 1;
+}
+int orc_add_texture_test(void* s) {
+    Texture t{}; t.type = TEX_TEST;
+    ((Scene*)s)->textures.push_back(t);
+    return (int)((Scene*)s)->textures.size() - 1;
+}
+int orc_add_texture_checker(void* s, float repeat, int odd, int even) {
+    Texture t{}; t.type = TEX_CHECKER; t.repeat = repeat; t.odd = odd; t.even = even;
+    ((Scene*)s)->textures.push_back(t);
+    return (int)((Scene*)s)->textures.size() - 1;
+}
+int orc_add_texture_image(void* s, uint32_t w, uint32_t h, uint32_t channels, const uint8_t* data) {
+    Texture t{}; t.type = TEX_IMAGE; t.w = w; t.h = h; t.ch = channels;
+    t.texels.assign(data, data + (size_t)w * h * channels);
+    ((Scene*)s)->textures.push_back(t);
+    return (int)((Scene*)s)->textures.size() - 1;
+}
+int orc_add_texture_noise(void* s, float scale) {
+    Texture t{}; t.type = TEX_NOISE; t.scale = scale;
+    ((Scene*)s)->textures.push_back(t);
+    return (int)((Scene*)s)->textures.size() - 1;
+}
+// texture.rs:162-173 : omega outside [0,1] is a load error
+int orc_add_texture_turbulence(void* s, float scale, uint32_t depth, float omega) {
+    Scene* sc = (Scene*)s;
+    if (omega > 1.0f) { sc->error = "Turbulence omega is greater than 1."; return -1; }
+    if (omega < 0.0f) { sc->error = "Turbulence omega is less than 0."; return -1; }
+    Texture t{}; t.type = TEX_TURBULENCE; t.scale = scale; t.depth = depth; t.omega = omega;
+    sc->textures.push_back(t);
+    return (int)sc->textures.size() - 1;
+}
+// material.rs constructors (scene.rs:263-407); Metal clamps roughness (material.rs:129-135)
+int orc_add_material(void* s, int type, int albedo, int bump, float param) {
+    Material m{type, albedo, bump, param};
+    if (type == MAT_METAL) {
+        if (m.param < 0.0f) m.param = 0.0f;
+        else if (m.param > 1.0f) m.param = 1.0f;
+    }
+    ((Scene*)s)->materials.push_back(m);
+    return (int)((Scene*)s)->materials.size() - 1;
+}
+
+static bool make_sphere(Scene* sc, const float* tr, const float* rot, const float* scl, float radius, int material, Shape* out) {
+    Shape sh{};
+    sh.type = SHAPE_SPHERE;
+    sh.l2w = transform_matrix(v3(tr[0], tr[1], tr[2]), v3(rot[0], rot[1], rot[2]), v3(scl[0], scl[1], scl[2]));
+    if (!m4_inverse(sh.l2w, &sh.w2l)) { sc->error = "Singular matrix"; return false; }  // shape.rs:56
+    sh.radius = radius;
+    sh.material = material;
+    sh.id = -1;
+    *out = sh;
+    return true;
+}
+// scene.rs:449-470
+int orc_add_sphere(void* s, const float* translate, const float* rotate, const float* scale, float radius, int material) {
+    Scene* sc = (Scene*)s;
+    Shape sh;
+    if (!make_sphere(sc, translate, rotate, scale, radius, material, &sh)) return -1;
+    sh.id = (int)sc->shapes.size();
+    sc->shapes.push_back(sh);
+    return sh.id;
+}
+// scene.rs:483-563 for ONE obj object; vertices in obj (local) space as f64 like wavefront_obj::Vertex.
+// vidx/tidx hold 3 entries per triangle; tidx entries < 0 mean "no texture index".
+// Returns the number of triangles added or -1 (error text in orc_scene_error).
+int orc_add_mesh(void* s, const float* translate, const float* rotate, const float* scale, uint32_t nverts, const double* verts, uint32_t ntex,
+                 const double* tex, uint32_t ntris, const int32_t* vidx, const int32_t* tidx, int cull, int material, int as_boundary) {
+    Scene* sc = (Scene*)s;
+    M4 l2w = transform_matrix(v3(translate[0], translate[1], translate[2]), v3(rotate[0], rotate[1], rotate[2]), v3(scale[0], scale[1], scale[2]));
+    Mesh m;
+    m.cull = cull != 0;
+    m.material = material;
+    for (uint32_t i = 0; i < nverts; ++i)  // point.rs:96-100 then scene.rs:507
+        m.vertices.push_back(m4_mul_point(l2w, v3((float)verts[3 * i], (float)verts[3 * i + 1], (float)verts[3 * i + 2])));
+    for (uint32_t i = 0; i < ntex; ++i) m.tex_coords.push_back(UV{(float)tex[2 * i], (float)tex[2 * i + 1]});  // scene.rs:512
+    sc->meshes.push_back(m);
+    int mesh_idx = (int)sc->meshes.size() - 1;
+    std::vector<Shape>& dst = as_boundary ? sc->boundaries : sc->shapes;
+    for (uint32_t k = 0; k < ntris; ++k) {
+        Shape t{};
+        t.type = SHAPE_TRIANGLE;
+        t.mesh = mesh_idx;
+        t.v0 = vidx[3 * k]; t.v1 = vidx[3 * k + 1]; t.v2 = vidx[3 * k + 2];
+        t.t0 = tidx ? tidx[3 * k] : -1; t.t1 = tidx ? tidx[3 * k + 1] : -1; t.t2 = tidx ? tidx[3 * k + 2] : -1;
+        t.material = material;
+        std::string err = triangle_new(*sc, &t);
+        if (!err.empty()) { sc->error = err; return -1; }
+        t.id = as_boundary ? -1 : (int)dst.size();
+        dst.push_back(t);
+    }
+    return (int)ntris;
+}
+// scene.rs:573-602 with a Sphere boundary
+int orc_add_medium_sphere(void* s, const float* translate, const float* rotate, const float* scale, float radius, int boundary_material,
+                          float density, int phase_material) {
+    Scene* sc = (Scene*)s;
+    Shape b;
+    if (!make_sphere(sc, translate, rotate, scale, radius, boundary_material, &b)) return -1;
+    sc->boundaries.push_back(b);
+    Shape m{};
+    m.type = SHAPE_MEDIUM;
+    m.boundary = (int)sc->boundaries.size() - 1;
+    m.density = density;
+    m.material = phase_material;
+    m.id = (int)sc->shapes.size();
+    sc->shapes.push_back(m);
+    return m.id;
+}
+// scene.rs:573-602 with the most recently added boundary triangle (orc_add_mesh(..., as_boundary=1) of exactly one triangle)
+int orc_add_medium_last_boundary(void* s, float density, int phase_material) {
+    Scene* sc = (Scene*)s;
+    if (sc->boundaries.empty()) { sc->error = "no boundary"; return -1; }
+    Shape m{};
+    m.type = SHAPE_MEDIUM;
+    m.boundary = (int)sc->boundaries.size() - 1;
+    m.density = density;
+    m.material = phase_material;
+    m.id = (int)sc->shapes.size();
+    sc->shapes.push_back(m);
+    return m.id;
+}
+// camera.rs:66-88
+void orc_set_camera(void* s, const float* pos, const float* look_at, const float* up, float fov, float aspect, float aperture, float focus) {
+    ((Scene*)s)->camera = camera_new(v3(pos[0], pos[1], pos[2]), v3(look_at[0], look_at[1], look_at[2]), v3(up[0], up[1], up[2]), fov, aspect,
+                                     aperture, focus);
+}
+// scene.rs:28-34
+void orc_set_logistics(void* s, uint32_t rx, uint32_t ry, uint32_t samples, int use_importance) {
+    Scene* sc = (Scene*)s;
+    sc->res_x = rx; sc->res_y = ry; sc->samples = samples; sc->use_importance = use_importance != 0;
+}
+// scene.rs:130-151, 605-619 ; aggregate 0 = "List", 1 = "BVH"
+int orc_finalize(void* s, int aggregate) {
+    Scene* sc = (Scene*)s;
+    sc->important.clear();
+    if (sc->use_importance)
+        for (size_t i = 0; i < sc->shapes.size(); ++i)
+            if (material_is_important(sc->materials[sc->shapes[i].material])) sc->important.push_back((int)i);
+    sc->aggregate = aggregate;
+    sc->bvh.clear();
+    if (aggregate == 1) {
+        std::vector<int> all(sc->shapes.size());
+        for (size_t i = 0; i < all.size(); ++i) all[i] = (int)i;
+        new_bvh_helper(*sc, sc->bvh, all);
+    }
+    return 0;
+}
+
+uint32_t orc_num_shapes(void* s) { return (uint32_t)((Scene*)s)->shapes.size(); }
+uint32_t orc_num_important(void* s) { return (uint32_t)((Scene*)s)->important.size(); }
+void orc_get_important(void* s, int32_t* out) {
+    Scene* sc = (Scene*)s;
+    for (size_t i = 0; i < sc->important.size(); ++i) out[i] = sc->important[i];
+}
+uint32_t orc_bvh_num_nodes(void* s) { return (uint32_t)((Scene*)s)->bvh.size(); }
+// Per node: box[6] = min xyz, max xyz; meta[4] = {leaf, cut_axis, right_offset, n_shapes}.  Returns total leaf shape count.
+uint32_t orc_bvh_export(void* s, float* boxes, int32_t* meta, int32_t* leaf_shapes) {
+    Scene* sc = (Scene*)s;
+    uint32_t k = 0;
+    for (size_t i = 0; i < sc->bvh.size(); ++i) {
+        const BvhNode& n = sc->bvh[i];
+        if (boxes) {
+            boxes[6 * i + 0] = n.box.min.x; boxes[6 * i + 1] = n.box.min.y; boxes[6 * i + 2] = n.box.min.z;
+            boxes[6 * i + 3] = n.box.max.x; boxes[6 * i + 4] = n.box.max.y; boxes[6 * i + 5] = n.box.max.z;
+        }
+        if (meta) {
+            meta[4 * i + 0] = n.leaf ? 1 : 0; meta[4 * i + 1] = n.cut_axis; meta[4 * i + 2] = (int32_t)n.right_offset; meta[4 * i + 3] = (int32_t)n.shapes.size();
+        }
+        for (int sh : n.shapes) {
+            if (leaf_shapes) leaf_shapes[k] = sh;
+            ++k;
+        }
+    }
+    return k;
+}
+void orc_get_camera(void* s, float* out19) {
+    const Camera& c = ((Scene*)s)->camera;
+    const V3* vs[6] = {&c.origin, &c.lower_left_corner, &c.horizontal, &c.vertical, &c.u, &c.v};
+    for (int i = 0; i < 6; ++i) { out19[3 * i] = vs[i]->x; out19[3 * i + 1] = vs[i]->y; out19[3 * i + 2] = vs[i]->z; }
+    out19[18] = c.lens_radius;
+}
+// Shape bounding boxes in scene order (shape.rs:129-139, 430-439)
+void orc_get_shape_bboxes(void* s, float* out6) {
+    Scene* sc = (Scene*)s;
+    for (size_t i = 0; i < sc->shapes.size(); ++i) {
+        AABB b = shape_bbox(*sc, sc->shapes[i]);
+        out6[6 * i + 0] = b.min.x; out6[6 * i + 1] = b.min.y; out6[6 * i + 2] = b.min.z;
+        out6[6 * i + 3] = b.max.x; out6[6 * i + 4] = b.max.y; out6[6 * i + 5] = b.max.z;
+    }
+}
+
+// Closest-hit queries for a ray batch (Aggregate::hit, aggregate.rs:118-124).
+// Ray i uses the keyed stream (seed, pixel=i, sample=0), depth 0, for stochastic primitives.
+// stats4 (optional) = {rays, nodes, tri_tests, sphere_tests}.
+void orc_intersect_batch(void* s, uint64_t n, const float* o, const float* d, float t_min, float t_max, int aabb_mode, uint32_t seed,
+                         int32_t* prim, float* t_hit, uint64_t* stats4) {
+    Scene* sc = (Scene*)s;
+    Workspace ws = get_workspace(*sc);
+    Stats st;
+    for (uint64_t i = 0; i < n; ++i) {
+        Ray r{v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2])};
+        Rng g = rng_seed(seed, (uint32_t)i, 0);
+        HitCtx cx{&g, 0, &st};
+        int shape;
+        float t;
+        st.rays++;
+        if (aggregate_hit(*sc, ws, r, t_min, t_max, aabb_mode, cx, &shape, &t)) {
+            prim[i] = shape;
+            t_hit[i] = t;
+        } else {
+            prim[i] = -1;
+            t_hit[i] = t_max;
+        }
+    }
+    if (stats4) { stats4[0] = st.rays; stats4[1] = st.nodes; stats4[2] = st.tri_tests; stats4[3] = st.sphere_tests; }
+}
+
+// Shape::get_hit_properties for (ray, prim, t): out14 = p[3] n[3] uv[2] pu[3] pv[3] (uv unclamped)
+void orc_hit_properties(void* s, uint64_t n, const float* o, const float* d, const int32_t* prim, const float* t, float* out14) {
+    Scene* sc = (Scene*)s;
+    for (uint64_t i = 0; i < n; ++i) {
+        float* q = out14 + 14 * i;
+        if (prim[i] < 0) { for (int k = 0; k < 14; ++k) q[k] = 0.0f; continue; }
+        Ray r{v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2])};
+        HitProps h = shape_hit_properties(*sc, sc->shapes[prim[i]], r, t[i]);
+        q[0] = h.p.x; q[1] = h.p.y; q[2] = h.p.z; q[3] = h.n.x; q[4] = h.n.y; q[5] = h.n.z; q[6] = h.uv.u; q[7] = h.uv.v;
+        q[8] = h.pu.x; q[9] = h.pu.y; q[10] = h.pu.z; q[11] = h.pv.x; q[12] = h.pv.y; q[13] = h.pv.z;
+    }
+}
+
+// Camera rays exactly as the render loop makes them (main.rs:227-229): out6 = origin, dir
+void orc_camera_rays(void* s, uint32_t W, uint32_t H, uint32_t seed, uint64_t n, const uint32_t* px, const uint32_t* py, const uint32_t* sample,
+                     float* out6) {
+    Scene* sc = (Scene*)s;
+    for (uint64_t i = 0; i < n; ++i) {
+        Rng g = rng_seed(seed, py[i] * W + px[i], sample[i]);
+        float u = ((float)px[i] + rng_f32(g)) / (float)W;
+        float v = ((float)(H - py[i]) + rng_f32(g)) / (float)H;
+        Ray r = camera_get_ray(sc->camera, u, v, g);
+        out6[6 * i + 0] = r.origin.x; out6[6 * i + 1] = r.origin.y; out6[6 * i + 2] = r.origin.z;
+        out6[6 * i + 3] = r.dir.x; out6[6 * i + 4] = r.dir.y; out6[6 * i + 5] = r.dir.z;
+    }
+}
+
+// The render loop: main.rs:150-157 (queue fill) + :200-257 (thread_work), without the queue/mutexes.
+// rgb_sum is row-major [y][x][3] (the reference's internal buffer is column-major x*res_y+y, main.rs:244).
+// flags: bit0 = recursive trace (faithful form) instead of the loop form; bit1 = complete slab test.
+// Rows are split over `threads` std::threads; each pixel sums its samples in sample order, so the
+// result does not depend on the thread count.  stats4 = {rays, nodes, tri_tests, sphere_tests}.
+void orc_render(void* s, uint32_t W, uint32_t H, uint32_t spp, uint32_t first_sample, uint32_t seed, int bg, int flags, int max_depth, int threads,
+                uint32_t y0, uint32_t y1, float* rgb_sum, uint64_t* stats4) {
+    Scene* sc = (Scene*)s;
+    if (threads < 1) threads = 1;
+    if (max_depth < 0) max_depth = kMaxDepth;
+    if (y1 > H) y1 = H;
+    TraceCfg cfg{bg, (flags & 2) ? 1 : 0, max_depth};
+    bool recursive = (flags & 1) != 0;
+    std::vector<Stats> stats((size_t)threads);
+    std::atomic<uint32_t> next_row(y0);
+    auto work = [&](int tid) {
+        Workspace ws = get_workspace(*sc);
+        Stats& st = stats[(size_t)tid];
+        for (;;) {
+            uint32_t y = next_row.fetch_add(1);
+            if (y >= y1) break;
+            for (uint32_t x = 0; x < W; ++x) {
+                RGB sum = v3(0, 0, 0);
+                for (uint32_t k = 0; k < spp; ++k) {
+                    Rng g = rng_seed(seed, y * W + x, first_sample + k);
+                    float u = ((float)x + rng_f32(g)) / (float)W;          // main.rs:227
+                    float v = ((float)(H - y) + rng_f32(g)) / (float)H;   // main.rs:228
+                    Ray r = camera_get_ray(sc->camera, u, v, g);
+                    RGB c = recursive ? trace_recursive(*sc, r, ws, g, cfg, st, 0) : trace_iterative(*sc, r, ws, g, cfg, st);
+                    sum = sum + c;  // main.rs:244-245
+                }
+                float* q = rgb_sum + ((size_t)y * W + x) * 3;
+                q[0] = sum.x; q[1] = sum.y; q[2] = sum.z;
+            }
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < threads; ++t) pool.emplace_back(work, t);
+    work(0);
+    for (auto& t : pool) t.join();
+    if (stats4) {
+        stats4[0] = stats4[1] = stats4[2] = stats4[3] = 0;
+        for (const Stats& st : stats) { stats4[0] += st.rays; stats4[1] += st.nodes; stats4[2] += st.tri_tests; stats4[3] += st.sphere_tests; }
+    }
+}
+
+// main.rs:173-186 : divide by samples, sqrt, * 255.99, `as u8` (saturating; NaN -> 0)
+void orc_resolve_rgb8(const float* rgb_sum, uint32_t W, uint32_t H, uint32_t spp, uint8_t* out) {
+    size_t n = (size_t)W * H * 3;
+    for (size_t i = 0; i < n; ++i) {
+        float c = rgb_sum[i] / (float)spp;
+        c = std::sqrt(c);
+        float b = c * kColorSpace;
+        uint8_t o;
+        if (b != b) o = 0;
+        else if (b <= 0.0f) o = 0;
+        else if (b >= 255.0f) o = 255;
+        else o = (uint8_t)b;
+        out[i] = o;
+    }
+}
+
+// ---- unit-level entry points for known-answer tests -----------------------
+int orc_unit_triangle_hit(const float* v0, const float* v1, const float* v2, int cull, const float* o, const float* d, float t_min, float t_max,
+                          float* t_out) {
+    Scene sc;
+    Mesh m; m.cull = cull != 0; m.material = 0;
+    m.vertices = {v3(v0[0], v0[1], v0[2]), v3(v1[0], v1[1], v1[2]), v3(v2[0], v2[1], v2[2])};
+    sc.meshes.push_back(m);
+    Shape t{}; t.type = SHAPE_TRIANGLE; t.mesh = 0; t.v0 = 0; t.v1 = 1; t.v2 = 2; t.t0 = t.t1 = t.t2 = -1;
+    Ray r{v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2])};
+    return triangle_hit(sc, t, r, t_min, t_max, t_out) ? 1 : 0;
+}
+int orc_unit_sphere_hit(const float* translate, const float* rotate, const float* scale, float radius, const float* o, const float* d, float t_min,
+                        float t_max, float* t_out) {
+    Scene sc;
+    Shape sh;
+    if (!make_sphere(&sc, translate, rotate, scale, radius, 0, &sh)) return -1;
+    Ray r{v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2])};
+    return sphere_hit(sh, r, t_min, t_max, t_out) ? 1 : 0;
+}
+int orc_unit_aabb_intersect(const float* bmin, const float* bmax, const float* o, const float* d, float t_min, float t_max, int mode) {
+    AABB b{v3(bmin[0], bmin[1], bmin[2]), v3(bmax[0], bmax[1], bmax[2])};
+    Ray r{v3(o[0], o[1], o[2]), v3(d[0], d[1], d[2])};
+    return (mode == 0 ? aabb_intersect(b, r, t_min, t_max) : aabb_intersect_tight(b, r, t_min, t_max)) ? 1 : 0;
+}
+float orc_unit_noise(float x, float y, float z) { return noise(v3(x, y, z)); }
+float orc_unit_turbulence(float x, float y, float z, uint32_t depth, float omega) { return turbulence(v3(x, y, z), depth, omega); }
+int orc_unit_matrix_inverse(const float* in16, float* out16) {
+    M4 m, r;
+    std::memcpy(m.d, in16, sizeof m.d);
+    if (!m4_inverse(m, &r)) return 0;
+    std::memcpy(out16, r.d, sizeof r.d);
+    return 1;
+}
+void orc_unit_transform_matrix(const float* translate, const float* rotate, const float* scale, float* out16) {
+    M4 m = transform_matrix(v3(translate[0], translate[1], translate[2]), v3(rotate[0], rotate[1], rotate[2]), v3(scale[0], scale[1], scale[2]));
+    std::memcpy(out16, m.d, sizeof m.d);
+}
+// which: 0 sin, 1 cos, 2 asin, 3 log, 4 atan2(x, y=aux)
+void orc_unit_detmath(int which, uint64_t n, const float* x, const float* aux, float* out) {
+    for (uint64_t i = 0; i < n; ++i) {
+        switch (which) {
+            case 0: out[i] = dm_sin(x[i]); break;
+            case 1: out[i] = dm_cos(x[i]); break;
+            case 2: out[i] = dm_asin(x[i]); break;
+            case 3: out[i] = dm_log(x[i]); break;
+            default: out[i] = dm_atan2(x[i], aux[i]); break;
+        }
+    }
+}
+// First n floats of the stream (seed, pixel, sample), then one index draw in [0, m) if idx_out != NULL.
+void orc_unit_rng(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t n, float* out, uint32_t m, uint32_t* idx_out, float* keyed_out) {
+    Rng g = rng_seed(seed, pixel, sample);
+    if (keyed_out) *keyed_out = rng_keyed_f32(g, 3, 7);
+    for (uint32_t i = 0; i < n; ++i) out[i] = rng_f32(g);
+    if (idx_out) *idx_out = rng_index(g, m);
+}
+// Samplers (utils.rs:10-49) driven by the stream (seed, pixel, sample): out = disk[3] sphere[3] cosine[3] to_sphere[3]
+void orc_unit_samplers(uint32_t seed, uint32_t pixel, uint32_t sample, float radius, float dist2, float* out12) {
+    Rng g = rng_seed(seed, pixel, sample);
+    V3 a = random_unit_disk(g), b = unit_sphere_random(g), c = random_cosine_direction(g), d = random_to_sphere(g, radius, dist2);
+    const V3* vs[4] = {&a, &b, &c, &d};
+    for (int i = 0; i < 4; ++i) { out12[3 * i] = vs[i]->x; out12[3 * i + 1] = vs[i]->y; out12[3 * i + 2] = vs[i]->z; }
+}
+// Texture::value (texture.rs) for n (uv, p) pairs
+void orc_texture_values(void* s, int tex, uint64_t n, const float* uv, const float* p, float* rgb) {
+    Scene* sc = (Scene*)s;
+    for (uint64_t i = 0; i < n; ++i) {
+        RGB c = texture_value(*sc, tex, UV{uv[2 * i], uv[2 * i + 1]}, v3(p[3 * i], p[3 * i + 1], p[3 * i + 2]));
+        rgb[3 * i] = c.x; rgb[3 * i + 1] = c.y; rgb[3 * i + 2] = c.z;
+    }
+}
+// Dielectric helpers (material.rs:15-30)
+void orc_unit_reflect_refract(const float* v, const float* n, float index, float* refl3, float* refr3, float* schlick_out, float cosine) {
+    V3 a = reflect(v3(v[0], v[1], v[2]), v3(n[0], n[1], n[2]));
+    V3 b = refract(v3(v[0], v[1], v[2]), v3(n[0], n[1], n[2]), index);
+    refl3[0] = a.x; refl3[1] = a.y; refl3[2] = a.z;
+    refr3[0] = b.x; refr3[1] = b.y; refr3[2] = b.z;
+    *schlick_out = schlick(cosine, index);
+}
+
+}  // extern "C"
