@@ -1,0 +1,269 @@
+/* rrt.h — C ABI of the MI355X path-tracing core (librrt_hip.so).
+ *
+ * The reference (trevday/rust-raytracer) is a single Rust binary with no FFI; the
+ * seams this library replaces are Rust-internal.  Each entry point below names the
+ * reference interface it stands in for (paths relative to the reference root).
+ *
+ * Conventions: every function returning int gives 0 on success and a non-zero
+ * rrt_status on failure, with rrt_last_error() returning a thread-local,
+ * NUL-terminated description.  Handles are opaque; one render at a time per
+ * handle.  All pointers are caller-owned unless stated.  Functions whose name
+ * ends in _device take HIP device pointers; `stream` is a hipStream_t passed as
+ * void* (NULL = the default stream).  The library operates on the calling
+ * thread's current HIP device.
+ */
+#ifndef RRT_H
+#define RRT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum rrt_status {
+    RRT_OK = 0,
+    RRT_ERR_INVALID = 1,   /* bad argument / malformed scene description */
+    RRT_ERR_SCENE = 2,     /* scene file could not be loaded (message mirrors scene.rs's DeserializeError text) */
+    RRT_ERR_DEVICE = 3,    /* HIP runtime failure */
+    RRT_ERR_LIMIT = 4,     /* scene exceeds a stated limit of this build (e.g. BVH deeper than the traversal stack) */
+    RRT_ERR_IO = 5         /* file system failure (e.g. output file already exists, main.rs:98-106) */
+} rrt_status;
+
+/* ---- flattened scene records (HBM layout; all 16-byte aligned) ---------------------------- */
+
+/* One BVH node, 32 bytes, 4 per 128-byte line.  Nodes are stored in the DFS pre-order that
+ * new_bvh_helper (aggregate.rs:193-322) produces: the left child of inner node i is i+1.
+ *   inner: a = absolute index of the right child (i + right_offset), b = cut axis (0,1,2)
+ *   leaf : a = first slot, b = 0x80000000 | slot count */
+typedef struct rrt_node {
+    float bmin[3];
+    uint32_t a;
+    float bmax[3];
+    uint32_t b;
+} rrt_node;
+#define RRT_LEAF_FLAG 0x80000000u
+
+/* One primitive slot, 48 bytes; slots are stored in leaf order (the order List::hit,
+ * aggregate.rs:144-165, walks a leaf).
+ *   triangle: v0, e1 = v1 - v0, e2 = v2 - v0 (the f32 differences Triangle::hit forms, shape.rs:340-341)
+ *   sphere / medium: v0,e1,e2 unused; aux = index into spheres[] / media[]
+ * info: bits 0..23 material index, bit 28 backface culling, bits 30..31 kind. */
+typedef struct rrt_slot {
+    float v0[3];
+    uint32_t prim; /* index of the shape in scene order (what Aggregate::hit's &SyncShape identifies) */
+    float e1[3];
+    uint32_t info;
+    float e2[3];
+    uint32_t aux;
+} rrt_slot;
+#define RRT_KIND_TRIANGLE 0u
+#define RRT_KIND_SPHERE 1u
+#define RRT_KIND_MEDIUM 2u
+#define RRT_INFO_CULL (1u << 28)
+#define RRT_INFO_KIND(info) ((info) >> 30)
+#define RRT_INFO_MATERIAL(info) ((info)&0x00ffffffu)
+
+/* Per-triangle shading record, 48 bytes, same index as the slot: texture coordinates
+ * (shape.rs:190-210 defaults applied) and the cached dp/du, dp/dv of Triangle::new (shape.rs:278-314). */
+typedef struct rrt_tri_shade {
+    float uv0[2], uv1[2], uv2[2];
+    float pu[3];
+    float pv[3];
+} rrt_tri_shade;
+
+/* Sphere (shape.rs:32-46): rows 0..2 of world_to_local and local_to_world (row-major 3x4), 128 bytes. */
+typedef struct rrt_sphere {
+    float w2l[12];
+    float l2w[12];
+    float radius;
+    uint32_t material;
+    uint32_t pad[6];
+} rrt_sphere;
+
+/* ConstantMedium (volume.rs:44-48).  boundary_kind is RRT_KIND_SPHERE (index into spheres[]) or
+ * RRT_KIND_TRIANGLE (index into boundary_tris[] / boundary_tri_shade[]). */
+typedef struct rrt_medium {
+    uint32_t boundary_kind;
+    uint32_t boundary_index;
+    float density;
+    uint32_t material; /* the phase function */
+} rrt_medium;
+
+typedef enum rrt_material_type {
+    RRT_MAT_LAMBERT = 0,       /* material.rs:84-115 */
+    RRT_MAT_METAL = 1,         /* material.rs:117-165 */
+    RRT_MAT_DIELECTRIC = 2,    /* material.rs:167-212 */
+    RRT_MAT_DIFFUSE_LIGHT = 3, /* material.rs:214-236 */
+    RRT_MAT_ISOTROPIC = 4      /* volume.rs:17-40 */
+} rrt_material_type;
+
+typedef struct rrt_material {
+    uint32_t type;
+    int32_t albedo; /* texture index: albedo or emission; -1 for Dielectric */
+    int32_t bump;   /* texture index or -1 */
+    float param;    /* Metal roughness (already clamped to [0,1]) or Dielectric refractive index */
+} rrt_material;
+
+typedef enum rrt_texture_type {
+    RRT_TEX_CONSTANT = 0,  /* a,b,c = r,g,b                         texture.rs:70-78  */
+    RRT_TEX_TEST = 1,      /*                                       texture.rs:80-93  */
+    RRT_TEX_CHECKER = 2,   /* a = repeat, u0 = odd, u1 = even       texture.rs:95-119 */
+    RRT_TEX_IMAGE = 3,     /* u0 = width, u1 = height, u2 = channels (1 or 3), u3 = byte offset into texels   texture.rs:121-141 */
+    RRT_TEX_NOISE = 4,     /* a = scale                             texture.rs:143-151 */
+    RRT_TEX_TURBULENCE = 5 /* a = scale, b = omega, u0 = depth      texture.rs:153-179 */
+} rrt_texture_type;
+
+typedef struct rrt_texture {
+    uint32_t type;
+    float a, b, c;
+    uint32_t u0, u1, u2, u3;
+} rrt_texture;
+
+/* One member of the light mixture (pdf.rs:85-115; members are PDF::Shape of every shape whose
+ * material is_important(), scene.rs:131-140, in scene order), 96 bytes.
+ *   triangle: v0,v1,v2 world-space vertices; e1,e2 as in rrt_slot; area = 0.5*|e1 x e2| (shape.rs:454)
+ *   sphere  : index into spheres[] */
+typedef struct rrt_light {
+    uint32_t kind;
+    uint32_t index;
+    uint32_t cull;
+    float area;
+    float v0[3], v1[3], v2[3];
+    float e1[3], e2[3];
+    float nrm[3]; /* normalized(e1 x e2), shape.rs:390 */
+    uint32_t pad[2];
+} rrt_light;
+
+/* Camera (camera.rs:11-19), as Camera::new (camera.rs:22-51) leaves it. */
+typedef struct rrt_camera {
+    float origin[3];
+    float lower_left_corner[3];
+    float horizontal[3];
+    float vertical[3];
+    float u[3];
+    float v[3];
+    float lens_radius;
+} rrt_camera;
+
+/* Everything the device needs, as host arrays.  ≙ the fields of scene::Scene (scene.rs:21-26) after
+ * scene::deserialize (scene.rs:64-159) and new_bvh (aggregate.rs:187-191). */
+typedef struct rrt_scene_desc {
+    uint32_t n_nodes;
+    const rrt_node* nodes;
+    uint32_t n_slots;
+    const rrt_slot* slots;
+    const rrt_tri_shade* tri_shade; /* n_slots entries */
+    uint32_t n_spheres;
+    const rrt_sphere* spheres;
+    uint32_t n_media;
+    const rrt_medium* media;
+    uint32_t n_boundary_tris;
+    const rrt_slot* boundary_tris;
+    const rrt_tri_shade* boundary_tri_shade;
+    uint32_t n_materials;
+    const rrt_material* materials;
+    uint32_t n_textures;
+    const rrt_texture* textures;
+    uint64_t texel_bytes;
+    const uint8_t* texels;
+    uint32_t n_lights;
+    const rrt_light* lights;
+    rrt_camera camera;
+    uint32_t resolution_x, resolution_y, samples; /* Logistics, scene.rs:28-34 */
+    uint32_t bvh_depth;                           /* maximum number of simultaneously pending stack entries + 1 */
+    uint32_t aggregate_is_list;                   /* "Aggregate": "List" (scene.rs:610): one leaf holding every shape in scene order */
+} rrt_scene_desc;
+
+typedef struct rrt_scene rrt_scene; /* device-resident scene */
+typedef struct rrt_host_scene rrt_host_scene; /* host-side builder / loader */
+
+enum { RRT_BG_BLACK = 0 /* main.rs:268-270 */, RRT_BG_SKY = 1 /* main.rs:259-267 */ };
+enum { RRT_AABB_TIGHT = 0 /* complete slab test, superset-safe */, RRT_AABB_REFERENCE = 1 /* aggregate.rs:471-503 verbatim */ };
+
+typedef struct rrt_render_params {
+    uint32_t width, height;   /* 0 = the scene's Logistics */
+    uint32_t samples;         /* samples per pixel rendered by this call; 0 = the scene's Logistics */
+    uint32_t first_sample;    /* index of the first sample in the per-pixel random stream (sample-range sharding) */
+    uint32_t seed;
+    uint32_t background;      /* RRT_BG_* */
+    int32_t max_depth;        /* < 0 = 50 (aggregate.rs:14) */
+    uint32_t aabb_mode;       /* RRT_AABB_* */
+    uint32_t tile_count;      /* interleaved 32x32-pixel tile sharding: this call renders tiles with index % tile_count == tile_index; 0/1 = all */
+    uint32_t tile_index;
+} rrt_render_params;
+
+typedef struct rrt_stats {
+    uint64_t rays;          /* Aggregate::hit calls made by trace (aggregate.rs:24) */
+    uint64_t paths;         /* camera samples traced */
+    double render_seconds;  /* kernel time on the stream (HIP events) for the host-buffer entry points; 0 for _device */
+} rrt_stats;
+
+/* ---- host side: scene construction -------------------------------------------------------- */
+
+/* ≙ scene::deserialize(&str, &Path, &mut Resources) (scene.rs:64-68) followed by the flattening.
+ * Logistics overrides: pass 0 / NaN to keep the file's value. */
+int rrt_host_scene_load(const char* scene_json_path, uint32_t override_width, uint32_t override_height, uint32_t override_samples,
+                        float override_aspect, rrt_host_scene** out);
+/* Programmatic construction, one call per scene.rs deserialize_* function. Indices returned through *id. */
+int rrt_host_scene_new(rrt_host_scene** out);
+int rrt_host_add_texture(rrt_host_scene*, const rrt_texture* t, const uint8_t* texels /* Image only: w*h*channels bytes */, int32_t* id);
+int rrt_host_add_material(rrt_host_scene*, uint32_t type, int32_t albedo, int32_t bump, float param, int32_t* id); /* scene.rs:263-407 */
+int rrt_host_add_sphere(rrt_host_scene*, const float translate[3], const float rotate[3], const float scale[3], float radius,
+                        int32_t material); /* scene.rs:449-470 */
+/* One .obj object (scene.rs:503-561): vertices in object space (f64 like wavefront_obj), 3 indices per triangle, tidx < 0 = none. */
+int rrt_host_add_mesh(rrt_host_scene*, const float translate[3], const float rotate[3], const float scale[3], uint32_t n_vertices,
+                      const double* vertices, uint32_t n_tex, const double* tex, uint32_t n_triangles, const int32_t* vidx,
+                      const int32_t* tidx, int cull, int32_t material);
+int rrt_host_add_medium_sphere(rrt_host_scene*, const float translate[3], const float rotate[3], const float scale[3], float radius,
+                               int32_t boundary_material, float density, int32_t phase_material); /* scene.rs:573-602 */
+int rrt_host_set_camera(rrt_host_scene*, const float position[3], const float look_at[3], const float up[3], float fov, float aspect,
+                        float aperture, float focus_distance); /* camera.rs:66-88 */
+int rrt_host_set_logistics(rrt_host_scene*, uint32_t resolution_x, uint32_t resolution_y, uint32_t samples, int use_importance_sampling);
+/* Builds the light list (scene.rs:130-140), the aggregate (scene.rs:605-619; aggregate.rs:187-322) and the flattened arrays. */
+int rrt_host_finalize(rrt_host_scene*, int aggregate_is_bvh);
+const rrt_scene_desc* rrt_host_desc(const rrt_host_scene*); /* valid after finalize/load, owned by the handle */
+void rrt_host_scene_destroy(rrt_host_scene*);
+
+/* ---- device side ---------------------------------------------------------------------------- */
+
+/* Uploads the flattened scene to the current device's HBM.  ≙ moving Scene into Arc (main.rs:85-95). */
+int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out);
+void rrt_scene_destroy(rrt_scene*);
+
+/* ≙ Aggregate::hit (aggregate.rs:118-124) for n rays: closest hit in (t_min, t_max).
+ * o_xyz, d_xyz: n*3 floats.  prim_id[i] = shape index in scene order or -1; t_hit[i] = distance (t_max on miss).
+ * Stochastic primitives (ConstantMedium) key their draw by (seed, ray index). */
+int rrt_intersect_batch(rrt_scene*, const float* o_xyz, const float* d_xyz, size_t n, float t_min, float t_max, uint32_t aabb_mode,
+                        uint32_t seed, int32_t* prim_id, float* t_hit);
+int rrt_intersect_batch_device(rrt_scene*, const float* d_o_xyz, const float* d_d_xyz, size_t n, float t_min, float t_max, uint32_t aabb_mode,
+                               uint32_t seed, int32_t* d_prim_id, float* d_t_hit, void* stream);
+
+/* ≙ queue fill + thread_work + join (main.rs:150-165, 200-257): accumulates params->samples samples of every
+ * pixel (of this call's tiles) and writes the per-pixel radiance SUM, row-major [y][x][3] f32 (pixels of other
+ * tiles are left untouched).  stats may be NULL. */
+int rrt_render(rrt_scene*, const rrt_render_params* params, float* rgb_sum, rrt_stats* stats);
+/* Same with a device output buffer; enqueues on `stream` and returns without synchronising.
+ * d_counters: optional device buffer of 2 uint64 {rays, paths} that the kernel adds to. */
+int rrt_render_device(rrt_scene*, const rrt_render_params* params, float* d_rgb_sum, uint64_t* d_counters, void* stream);
+
+/* ≙ main.rs:173-186: out[i] = (u8)(sqrt(sum[i] / spp) * 255.99), saturating, NaN -> 0.  Host buffers. */
+int rrt_resolve_rgb8(const float* rgb_sum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* out);
+int rrt_resolve_rgb8_device(const float* d_rgb_sum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_out, void* stream);
+
+/* Device-side unit probes used by the parity tests (each ≙ the named reference function, evaluated on the GPU):
+ *   which = 0 camera rays for (px,py,sample) triples in `in` (3 u32 each) -> 6 floats            (main.rs:227-229, camera.rs:53-63)
+ *           1 Shape::get_hit_properties for (o,d,prim,t) (8 x 4 bytes each) -> 14 floats         (shape.rs:87-123, 374-424)
+ *           2 Texture::value for texture `arg` at (u,v,px,py,pz) -> 3 floats                     (texture.rs:61-179)
+ *           3 deterministic sin,cos,asin,log,atan2(x,y) for (x,y) -> 5 floats
+ *           4 first 8 floats of stream (seed=arg, pixel, sample) for (pixel,sample) -> 8 floats */
+int rrt_probe(rrt_scene*, uint32_t which, uint32_t arg, const void* in, size_t n, float* out);
+
+const char* rrt_last_error(void);
+const char* rrt_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RRT_H */

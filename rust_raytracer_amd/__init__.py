@@ -1,0 +1,346 @@
+"""rust_raytracer_amd — MI355X path-tracing core behind the trevday/rust-raytracer scene format.
+
+Thin ctypes binding of librrt_hip.so (C ABI in include/rrt.h).  There is no CPU fallback: if the
+library is missing this module raises at first use.  Names follow the reference: a `Scene` is what
+scene::deserialize returns (scene.rs:64-68), `Scene.hit` is Aggregate::hit (aggregate.rs:118-124),
+`Scene.render` is the queue-fill + thread_work loop (main.rs:150-165, 200-257) and `resolve_rgb8`
+is the final conversion (main.rs:173-186).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librrt_hip.so")
+
+BG_BLACK, BG_SKY = 0, 1
+AABB_TIGHT, AABB_REFERENCE = 0, 1
+KIND_TRIANGLE, KIND_SPHERE, KIND_MEDIUM = 0, 1, 2
+T_MIN = 0.001
+T_MAX = float(np.finfo(np.float32).max)
+
+
+class RrtError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("rrt error %d: %s" % (code, message))
+        self.code = code
+        self.message = message
+
+
+class _Node(C.Structure):
+    _fields_ = [("bmin", C.c_float * 3), ("a", C.c_uint32), ("bmax", C.c_float * 3), ("b", C.c_uint32)]
+
+
+class _Slot(C.Structure):
+    _fields_ = [("v0", C.c_float * 3), ("prim", C.c_uint32), ("e1", C.c_float * 3), ("info", C.c_uint32), ("e2", C.c_float * 3), ("aux", C.c_uint32)]
+
+
+class _TriShade(C.Structure):
+    _fields_ = [("uv0", C.c_float * 2), ("uv1", C.c_float * 2), ("uv2", C.c_float * 2), ("pu", C.c_float * 3), ("pv", C.c_float * 3)]
+
+
+class _Sphere(C.Structure):
+    _fields_ = [("w2l", C.c_float * 12), ("l2w", C.c_float * 12), ("radius", C.c_float), ("material", C.c_uint32), ("pad", C.c_uint32 * 6)]
+
+
+class _Medium(C.Structure):
+    _fields_ = [("boundary_kind", C.c_uint32), ("boundary_index", C.c_uint32), ("density", C.c_float), ("material", C.c_uint32)]
+
+
+class _Material(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("albedo", C.c_int32), ("bump", C.c_int32), ("param", C.c_float)]
+
+
+class _Texture(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("a", C.c_float), ("b", C.c_float), ("c", C.c_float), ("u0", C.c_uint32), ("u1", C.c_uint32),
+                ("u2", C.c_uint32), ("u3", C.c_uint32)]
+
+
+class _Light(C.Structure):
+    _fields_ = [("kind", C.c_uint32), ("index", C.c_uint32), ("cull", C.c_uint32), ("area", C.c_float), ("v0", C.c_float * 3),
+                ("v1", C.c_float * 3), ("v2", C.c_float * 3), ("e1", C.c_float * 3), ("e2", C.c_float * 3), ("nrm", C.c_float * 3),
+                ("pad", C.c_uint32 * 2)]
+
+
+class _Camera(C.Structure):
+    _fields_ = [("origin", C.c_float * 3), ("lower_left_corner", C.c_float * 3), ("horizontal", C.c_float * 3), ("vertical", C.c_float * 3),
+                ("u", C.c_float * 3), ("v", C.c_float * 3), ("lens_radius", C.c_float)]
+
+
+class _SceneDesc(C.Structure):
+    _fields_ = [("n_nodes", C.c_uint32), ("nodes", C.POINTER(_Node)), ("n_slots", C.c_uint32), ("slots", C.POINTER(_Slot)),
+                ("tri_shade", C.POINTER(_TriShade)), ("n_spheres", C.c_uint32), ("spheres", C.POINTER(_Sphere)), ("n_media", C.c_uint32),
+                ("media", C.POINTER(_Medium)), ("n_boundary_tris", C.c_uint32), ("boundary_tris", C.POINTER(_Slot)),
+                ("boundary_tri_shade", C.POINTER(_TriShade)), ("n_materials", C.c_uint32), ("materials", C.POINTER(_Material)),
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(_Texture)), ("texel_bytes", C.c_uint64), ("texels", C.POINTER(C.c_uint8)),
+                ("n_lights", C.c_uint32), ("lights", C.POINTER(_Light)), ("camera", _Camera), ("resolution_x", C.c_uint32),
+                ("resolution_y", C.c_uint32), ("samples", C.c_uint32), ("bvh_depth", C.c_uint32), ("aggregate_is_list", C.c_uint32)]
+
+
+class _RenderParams(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples", C.c_uint32), ("first_sample", C.c_uint32), ("seed", C.c_uint32),
+                ("background", C.c_uint32), ("max_depth", C.c_int32), ("aabb_mode", C.c_uint32), ("tile_count", C.c_uint32),
+                ("tile_index", C.c_uint32)]
+
+
+class _Stats(C.Structure):
+    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("render_seconds", C.c_double)]
+
+
+_lib = None
+_f3 = C.c_float * 3
+
+
+def lib():
+    """Loads librrt_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("librrt_hip.so has not been built (run `python rust_raytracer_amd/build.py`); there is no CPU fallback")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.rrt_last_error.restype = C.c_char_p
+    L.rrt_version.restype = C.c_char_p
+    L.rrt_host_scene_load.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.POINTER(vp)]
+    L.rrt_host_scene_new.argtypes = [C.POINTER(vp)]
+    L.rrt_host_add_texture.argtypes = [vp, C.POINTER(_Texture), vp, C.POINTER(C.c_int32)]
+    L.rrt_host_add_material.argtypes = [vp, C.c_uint32, C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_int32)]
+    L.rrt_host_add_sphere.argtypes = [vp, _f3, _f3, _f3, C.c_float, C.c_int32]
+    L.rrt_host_add_mesh.argtypes = [vp, _f3, _f3, _f3, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_int, C.c_int32]
+    L.rrt_host_add_medium_sphere.argtypes = [vp, _f3, _f3, _f3, C.c_float, C.c_int32, C.c_float, C.c_int32]
+    L.rrt_host_set_camera.argtypes = [vp, _f3, _f3, _f3, C.c_float, C.c_float, C.c_float, C.c_float]
+    L.rrt_host_set_logistics.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
+    L.rrt_host_finalize.argtypes = [vp, C.c_int]
+    L.rrt_host_desc.argtypes = [vp]
+    L.rrt_host_desc.restype = C.POINTER(_SceneDesc)
+    L.rrt_host_scene_destroy.argtypes = [vp]
+    L.rrt_scene_create.argtypes = [C.POINTER(_SceneDesc), C.POINTER(vp)]
+    L.rrt_scene_destroy.argtypes = [vp]
+    L.rrt_intersect_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
+    L.rrt_intersect_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
+    L.rrt_render.argtypes = [vp, C.POINTER(_RenderParams), vp, C.POINTER(_Stats)]
+    L.rrt_render_device.argtypes = [vp, C.POINTER(_RenderParams), vp, vp, vp]
+    L.rrt_resolve_rgb8.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
+    L.rrt_resolve_rgb8_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
+    L.rrt_probe.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RrtError(rc, lib().rrt_last_error().decode(errors="replace"))
+
+
+def version():
+    return lib().rrt_version().decode()
+
+
+def _vec(v):
+    return _f3(float(v[0]), float(v[1]), float(v[2]))
+
+
+class HostScene:
+    """The scene as scene::deserialize builds it (shapes, light list, SAH BVH), flattened for the device."""
+
+    def __init__(self, handle):
+        self._h = handle
+
+    @classmethod
+    def load(cls, path, width=0, height=0, samples=0, aspect_ratio=float("nan")):
+        h = C.c_void_p()
+        _check(lib().rrt_host_scene_load(os.fsencode(path), width, height, samples, aspect_ratio, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def new(cls):
+        h = C.c_void_p()
+        _check(lib().rrt_host_scene_new(C.byref(h)))
+        return cls(h)
+
+    # builder calls, one per scene.rs deserialize_* function
+    def add_texture(self, type, a=0.0, b=0.0, c=0.0, u0=0, u1=0, u2=0, texels=None):
+        t = _Texture(type, a, b, c, u0, u1, u2, 0)
+        tid = C.c_int32(-1)
+        px = None
+        if texels is not None:
+            texels = np.ascontiguousarray(texels, dtype=np.uint8)
+            px = texels.ctypes.data
+        _check(lib().rrt_host_add_texture(self._h, C.byref(t), px, C.byref(tid)))
+        return tid.value
+
+    def add_material(self, type, albedo=-1, bump=-1, param=0.0):
+        mid = C.c_int32(-1)
+        _check(lib().rrt_host_add_material(self._h, type, albedo, bump, param, C.byref(mid)))
+        return mid.value
+
+    def add_sphere(self, radius, material, translate=(0, 0, 0), rotate=(0, 0, 0), scale=(1, 1, 1)):
+        _check(lib().rrt_host_add_sphere(self._h, _vec(translate), _vec(rotate), _vec(scale), radius, material))
+
+    def add_mesh(self, vertices, triangles, material, cull=False, tex=None, tex_triangles=None, translate=(0, 0, 0), rotate=(0, 0, 0),
+                 scale=(1, 1, 1)):
+        v = np.ascontiguousarray(vertices, dtype=np.float64).reshape(-1, 3)
+        vi = np.ascontiguousarray(triangles, dtype=np.int32).reshape(-1, 3)
+        t = np.ascontiguousarray(tex, dtype=np.float64).reshape(-1, 2) if tex is not None else np.zeros((0, 2))
+        ti = np.ascontiguousarray(tex_triangles, dtype=np.int32).reshape(-1, 3) if tex_triangles is not None else None
+        _check(lib().rrt_host_add_mesh(self._h, _vec(translate), _vec(rotate), _vec(scale), len(v), v.ctypes.data, len(t),
+                                       t.ctypes.data if len(t) else None, len(vi), vi.ctypes.data, ti.ctypes.data if ti is not None else None,
+                                       1 if cull else 0, material))
+
+    def add_medium_sphere(self, radius, boundary_material, density, phase_material, translate=(0, 0, 0), rotate=(0, 0, 0), scale=(1, 1, 1)):
+        _check(lib().rrt_host_add_medium_sphere(self._h, _vec(translate), _vec(rotate), _vec(scale), radius, boundary_material, density,
+                                                phase_material))
+
+    def set_camera(self, position, look_at, up, fov, aspect_ratio, aperture, focus_distance):
+        _check(lib().rrt_host_set_camera(self._h, _vec(position), _vec(look_at), _vec(up), fov, aspect_ratio, aperture, focus_distance))
+
+    def set_logistics(self, resolution_x, resolution_y, samples, use_importance_sampling=True):
+        _check(lib().rrt_host_set_logistics(self._h, resolution_x, resolution_y, samples, 1 if use_importance_sampling else 0))
+
+    def finalize(self, aggregate="BVH"):
+        _check(lib().rrt_host_finalize(self._h, 1 if aggregate == "BVH" else 0))
+
+    @property
+    def desc(self):
+        d = lib().rrt_host_desc(self._h)
+        if not d:
+            raise RrtError(1, lib().rrt_last_error().decode())
+        return d.contents
+
+    # flattened arrays as numpy (copies), for inspection and tests
+    def nodes(self):
+        d = self.desc
+        out = np.zeros(d.n_nodes, dtype=[("bmin", "f4", 3), ("a", "u4"), ("bmax", "f4", 3), ("b", "u4")])
+        if d.n_nodes:
+            C.memmove(out.ctypes.data, d.nodes, out.nbytes)
+        return out
+
+    def slots(self):
+        d = self.desc
+        out = np.zeros(d.n_slots, dtype=[("v0", "f4", 3), ("prim", "u4"), ("e1", "f4", 3), ("info", "u4"), ("e2", "f4", 3), ("aux", "u4")])
+        if d.n_slots:
+            C.memmove(out.ctypes.data, d.slots, out.nbytes)
+        return out
+
+    def lights(self):
+        d = self.desc
+        out = np.zeros(d.n_lights, dtype=[("kind", "u4"), ("index", "u4"), ("cull", "u4"), ("area", "f4"), ("v0", "f4", 3), ("v1", "f4", 3),
+                                          ("v2", "f4", 3), ("e1", "f4", 3), ("e2", "f4", 3), ("nrm", "f4", 3), ("pad", "u4", 2)])
+        if d.n_lights:
+            C.memmove(out.ctypes.data, d.lights, out.nbytes)
+        return out
+
+    def textures(self):
+        d = self.desc
+        out = np.zeros(d.n_textures, dtype=[("type", "u4"), ("a", "f4"), ("b", "f4"), ("c", "f4"), ("u0", "u4"), ("u1", "u4"), ("u2", "u4"),
+                                            ("u3", "u4")])
+        if d.n_textures:
+            C.memmove(out.ctypes.data, d.textures, out.nbytes)
+        return out
+
+    def texels(self):
+        d = self.desc
+        out = np.zeros(d.texel_bytes, dtype=np.uint8)
+        if d.texel_bytes:
+            C.memmove(out.ctypes.data, d.texels, out.nbytes)
+        return out
+
+    def camera(self):
+        c = self.desc.camera
+        return np.array(list(c.origin) + list(c.lower_left_corner) + list(c.horizontal) + list(c.vertical) + list(c.u) + list(c.v)
+                        + [c.lens_radius], dtype=np.float32)
+
+    def close(self):
+        if self._h:
+            lib().rrt_host_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Scene:
+    """A scene resident in the current GPU's HBM."""
+
+    def __init__(self, host):
+        self.host = host
+        d = host.desc
+        self.width, self.height, self.samples = d.resolution_x, d.resolution_y, d.samples
+        h = C.c_void_p()
+        _check(lib().rrt_scene_create(C.byref(d), C.byref(h)))
+        self._h = h
+
+    @classmethod
+    def load(cls, path, width=0, height=0, samples=0, aspect_ratio=float("nan")):
+        return cls(HostScene.load(path, width, height, samples, aspect_ratio))
+
+    def hit(self, origins, directions, t_min=T_MIN, t_max=T_MAX, aabb_mode=AABB_TIGHT, seed=0):
+        """Aggregate::hit for a batch of rays: (prim_id int32[n] with -1 = miss, t float32[n])."""
+        o = np.ascontiguousarray(origins, dtype=np.float32).reshape(-1, 3)
+        d = np.ascontiguousarray(directions, dtype=np.float32).reshape(-1, 3)
+        if len(o) != len(d):
+            raise ValueError("origins and directions differ in length")
+        prim = np.full(len(o), -1, dtype=np.int32)
+        t = np.zeros(len(o), dtype=np.float32)
+        _check(lib().rrt_intersect_batch(self._h, o.ctypes.data, d.ctypes.data, len(o), t_min, t_max, aabb_mode, seed, prim.ctypes.data,
+                                         t.ctypes.data))
+        return prim, t
+
+    def _params(self, width, height, samples, first_sample, seed, background, max_depth, aabb_mode, tile_count, tile_index):
+        return _RenderParams(width or 0, height or 0, samples or 0, first_sample, seed, background, max_depth, aabb_mode, tile_count,
+                             tile_index)
+
+    def render(self, width=None, height=None, samples=None, first_sample=0, seed=0, background=BG_BLACK, max_depth=-1,
+               aabb_mode=AABB_TIGHT, tile_count=1, tile_index=0, out=None):
+        """Per-pixel radiance sums, float32 [H, W, 3], and the stats dict (rays, paths, seconds)."""
+        W, H = width or self.width, height or self.height
+        img = out if out is not None else np.zeros((H, W, 3), dtype=np.float32)
+        if img.shape != (H, W, 3) or img.dtype != np.float32 or not img.flags["C_CONTIGUOUS"]:
+            raise ValueError("out must be a C-contiguous float32 array of shape (H, W, 3)")
+        p = self._params(width, height, samples, first_sample, seed, background, max_depth, aabb_mode, tile_count, tile_index)
+        st = _Stats()
+        _check(lib().rrt_render(self._h, C.byref(p), img.ctypes.data, C.byref(st)))
+        return img, {"rays": st.rays, "paths": st.paths, "seconds": st.render_seconds}
+
+    def render_device(self, d_rgb_sum, d_counters=0, stream=0, **kw):
+        """Enqueues the render on `stream` into a device buffer (raw pointers as ints); does not synchronise."""
+        p = self._params(kw.get("width"), kw.get("height"), kw.get("samples"), kw.get("first_sample", 0), kw.get("seed", 0),
+                         kw.get("background", BG_BLACK), kw.get("max_depth", -1), kw.get("aabb_mode", AABB_TIGHT), kw.get("tile_count", 1),
+                         kw.get("tile_index", 0))
+        _check(lib().rrt_render_device(self._h, C.byref(p), d_rgb_sum, d_counters or None, stream or None))
+
+    def probe(self, which, arg, inp, out_words):
+        inp = np.ascontiguousarray(inp)
+        n = inp.shape[0]
+        out = np.zeros((n, out_words), dtype=np.float32)
+        _check(lib().rrt_probe(self._h, which, arg, inp.ctypes.data, n, out.ctypes.data))
+        return out
+
+    def close(self):
+        if self._h:
+            lib().rrt_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def resolve_rgb8(rgb_sum, spp):
+    """main.rs:173-186 on the GPU: uint8 [H, W, 3]."""
+    a = np.ascontiguousarray(rgb_sum, dtype=np.float32)
+    H, W, _ = a.shape
+    out = np.zeros((H, W, 3), dtype=np.uint8)
+    _check(lib().rrt_resolve_rgb8(a.ctypes.data, W, H, spp, out.ctypes.data))
+    return out
+
+
+def resolve_rgb8_device(d_rgb_sum, width, height, spp, d_out, stream=0):
+    _check(lib().rrt_resolve_rgb8_device(d_rgb_sum, width, height, spp, d_out, stream or None))

@@ -1,0 +1,405 @@
+// JPEG (baseline sequential, 8-bit) and PNG (non-interlaced) decoders for Image textures
+// (texture.rs:121-141 reads texels through image::open, resources.rs:41).
+//
+// The JPEG path follows the IJG integer pipeline — the "slow but accurate" 8x8 inverse DCT with 13-bit
+// constants and the 16-bit fixed-point YCbCr->RGB tables — so that decoded texels agree with the widely
+// deployed libjpeg decoders for non-subsampled and greyscale files.  Chroma-subsampled files are upsampled
+// by replication.  The reference's own decoder (jpeg-decoder 0.1.18) is not part of the reference tree and
+// may differ by one code value per texel.
+#include <zlib.h>
+
+#include <cstring>
+
+#include "scene_host.hpp"
+
+namespace rrt_host {
+
+namespace {
+
+struct Huff {
+    // canonical code tables: for each code length, the smallest code and the index of its first symbol
+    int mincode[17], maxcode[18], valptr[17];
+    uint8_t vals[256];
+    bool present = false;
+};
+
+struct Component {
+    int id = 0, h = 1, v = 1, tq = 0, td = 0, ta = 0;
+    int pred = 0;
+    int bw = 0, bh = 0;  // blocks per row / column in the padded plane
+    std::vector<uint8_t> plane;
+};
+
+struct JpegReader {
+    const uint8_t* p;
+    const uint8_t* end;
+    uint32_t bitbuf = 0;
+    int bitcnt = 0;
+    bool hit_marker = false;
+
+    int next_byte() {
+        if (p >= end) return -1;
+        return *p++;
+    }
+    void fill() {
+        while (bitcnt <= 24) {
+            int b = 0;
+            if (!hit_marker && p < end) {
+                b = *p;
+                if (b == 0xFF) {
+                    if (p + 1 < end && p[1] == 0x00) {
+                        p += 2;
+                    } else {
+                        hit_marker = true;  // leave the marker for the caller; feed zeros
+                        b = 0;
+                    }
+                } else {
+                    ++p;
+                }
+            } else {
+                b = 0;
+            }
+            bitbuf |= (uint32_t)b << (24 - bitcnt);
+            bitcnt += 8;
+        }
+    }
+    int get_bits(int n) {
+        if (n == 0) return 0;
+        if (bitcnt < n) fill();
+        int v = (int)(bitbuf >> (32 - n));
+        bitbuf <<= n;
+        bitcnt -= n;
+        return v;
+    }
+    int decode(const Huff& h) {
+        int code = 0;
+        for (int len = 1; len <= 16; ++len) {
+            code = (code << 1) | get_bits(1);
+            if (h.maxcode[len] >= 0 && code <= h.maxcode[len] && code >= h.mincode[len]) return h.vals[h.valptr[len] + code - h.mincode[len]];
+        }
+        return -1;
+    }
+    void reset_bits() {
+        bitbuf = 0;
+        bitcnt = 0;
+        hit_marker = false;
+    }
+};
+
+int extend(int v, int n) { return v < (1 << (n - 1)) ? v - (1 << n) + 1 : v; }
+
+const int kZigzag[64] = {0,  1,  8,  16, 9,  2,  3,  10, 17, 24, 32, 25, 18, 11, 4,  5,  12, 19, 26, 33, 40, 48,
+                         41, 34, 27, 20, 13, 6,  7,  14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23,
+                         30, 37, 44, 51, 58, 59, 52, 45, 38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+
+inline int descale(long x, int n) { return (int)((x + (1L << (n - 1))) >> n); }
+inline uint8_t clamp8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+// 8x8 inverse DCT, 13-bit fixed point, two passes with 2 extra bits kept between them.
+void idct_block(const int* coef, const uint16_t* quant, uint8_t* out, int stride) {
+    const int CB = 13, P1 = 2;
+    const long F_0_298 = 2446, F_0_390 = 3196, F_0_541 = 4433, F_0_765 = 6270, F_0_899 = 7373, F_1_175 = 9633, F_1_501 = 12299, F_1_847 = 15137,
+               F_1_961 = 16069, F_2_053 = 16819, F_2_562 = 20995, F_3_072 = 25172;
+    long ws[64];
+    for (int pass = 0; pass < 2; ++pass) {
+        for (int i = 0; i < 8; ++i) {
+            long in[8];
+            for (int k = 0; k < 8; ++k) in[k] = pass == 0 ? (long)coef[k * 8 + i] * quant[k * 8 + i] : ws[i * 8 + k];
+            long z2 = in[2], z3 = in[6];
+            long z1 = (z2 + z3) * F_0_541;
+            long t2 = z1 + z3 * (-F_1_847);
+            long t3 = z1 + z2 * F_0_765;
+            long t0 = (in[0] + in[4]) << CB;
+            long t1 = (in[0] - in[4]) << CB;
+            long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
+            t0 = in[7]; t1 = in[5]; t2 = in[3]; t3 = in[1];
+            z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2;
+            long z4 = t1 + t3;
+            long z5 = (z3 + z4) * F_1_175;
+            t0 *= F_0_298; t1 *= F_2_053; t2 *= F_3_072; t3 *= F_1_501;
+            z1 *= -F_0_899; z2 *= -F_2_562; z3 *= -F_1_961; z4 *= -F_0_390;
+            z3 += z5; z4 += z5;
+            t0 += z1 + z3; t1 += z2 + z4; t2 += z2 + z3; t3 += z1 + z4;
+            long o[8] = {t10 + t3, t11 + t2, t12 + t1, t13 + t0, t13 - t0, t12 - t1, t11 - t2, t10 - t3};
+            if (pass == 0) {
+                for (int k = 0; k < 8; ++k) ws[k * 8 + i] = descale(o[k], CB - P1);
+            } else {
+                for (int k = 0; k < 8; ++k) out[i * stride + k] = clamp8(descale(o[k], CB + P1 + 3) + 128);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+std::string decode_jpeg(const std::vector<uint8_t>& f, uint32_t* w, uint32_t* h, uint32_t* channels, std::vector<uint8_t>* px) {
+    uint16_t quant[4][64] = {};
+    Huff dc[4], ac[4];
+    Component comp[4];
+    int ncomp = 0, width = 0, height = 0, restart_interval = 0;
+    bool have_frame = false;
+    size_t i = 2;
+    auto be16 = [&](size_t at) { return (int)((f[at] << 8) | f[at + 1]); };
+    while (i + 4 <= f.size()) {
+        if (f[i] != 0xFF) return "JPEG: expected a marker";
+        int marker = f[i + 1];
+        i += 2;
+        if (marker == 0xD8 || (marker >= 0xD0 && marker <= 0xD7) || marker == 0x01 || marker == 0xFF) {
+            if (marker == 0xFF) --i;
+            continue;
+        }
+        if (marker == 0xD9) break;
+        if (i + 2 > f.size()) return "JPEG: truncated segment";
+        int len = be16(i);
+        if (len < 2 || i + (size_t)len > f.size()) return "JPEG: bad segment length";
+        size_t seg = i + 2, seg_end = i + (size_t)len;
+        if (marker == 0xDB) {  // quantisation tables
+            while (seg < seg_end) {
+                int pq = f[seg] >> 4, tq = f[seg] & 15;
+                ++seg;
+                if (tq > 3) return "JPEG: bad quantisation table id";
+                for (int k = 0; k < 64; ++k) {
+                    if (seg + (pq ? 2 : 1) > seg_end) return "JPEG: truncated quantisation table";
+                    quant[tq][kZigzag[k]] = (uint16_t)(pq ? be16(seg) : f[seg]);
+                    seg += pq ? 2 : 1;
+                }
+            }
+        } else if (marker == 0xC4) {  // Huffman tables
+            while (seg < seg_end) {
+                int tc = f[seg] >> 4, th = f[seg] & 15;
+                ++seg;
+                if (th > 3 || tc > 1 || seg + 16 > seg_end) return "JPEG: bad Huffman table";
+                Huff& t = tc ? ac[th] : dc[th];
+                int counts[17] = {0};
+                int total = 0;
+                for (int k = 1; k <= 16; ++k) {
+                    counts[k] = f[seg + k - 1];
+                    total += counts[k];
+                }
+                seg += 16;
+                if (total > 256 || seg + (size_t)total > seg_end) return "JPEG: bad Huffman table";
+                std::memcpy(t.vals, &f[seg], (size_t)total);
+                seg += (size_t)total;
+                int code = 0, k = 0;
+                for (int l = 1; l <= 16; ++l) {
+                    t.valptr[l] = k;
+                    t.mincode[l] = code;
+                    code += counts[l];
+                    k += counts[l];
+                    t.maxcode[l] = counts[l] ? code - 1 : -1;
+                    code <<= 1;
+                }
+                t.present = true;
+            }
+        } else if (marker == 0xC0 || marker == 0xC1) {  // baseline / extended sequential, Huffman
+            if (f[seg] != 8) return "JPEG: only 8-bit samples are supported";
+            height = be16(seg + 1);
+            width = be16(seg + 3);
+            ncomp = f[seg + 5];
+            if (width <= 0 || height <= 0 || (ncomp != 1 && ncomp != 3)) return "JPEG: unsupported frame";
+            for (int c = 0; c < ncomp; ++c) {
+                comp[c].id = f[seg + 6 + 3 * c];
+                comp[c].h = f[seg + 7 + 3 * c] >> 4;
+                comp[c].v = f[seg + 7 + 3 * c] & 15;
+                comp[c].tq = f[seg + 8 + 3 * c];
+                if (comp[c].h < 1 || comp[c].h > 2 || comp[c].v < 1 || comp[c].v > 2 || comp[c].tq > 3) return "JPEG: unsupported sampling";
+            }
+            have_frame = true;
+        } else if (marker == 0xC2) {
+            return "JPEG: progressive files are not supported";
+        } else if (marker == 0xDD) {
+            restart_interval = be16(seg);
+        } else if (marker == 0xDA) {  // start of scan: decode the whole (single, interleaved) scan
+            if (!have_frame) return "JPEG: scan before frame";
+            int ns = f[seg];
+            if (ns != ncomp) return "JPEG: multi-scan files are not supported";
+            for (int k = 0; k < ns; ++k) {
+                int cid = f[seg + 1 + 2 * k];
+                for (int c = 0; c < ncomp; ++c)
+                    if (comp[c].id == cid) {
+                        comp[c].td = f[seg + 2 + 2 * k] >> 4;
+                        comp[c].ta = f[seg + 2 + 2 * k] & 15;
+                    }
+            }
+            int hmax = 1, vmax = 1;
+            for (int c = 0; c < ncomp; ++c) {
+                hmax = comp[c].h > hmax ? comp[c].h : hmax;
+                vmax = comp[c].v > vmax ? comp[c].v : vmax;
+            }
+            if (ncomp == 1) comp[0].h = comp[0].v = hmax = vmax = 1;
+            int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+            for (int c = 0; c < ncomp; ++c) {
+                comp[c].bw = mcux * comp[c].h;
+                comp[c].bh = mcuy * comp[c].v;
+                comp[c].plane.assign((size_t)comp[c].bw * 8 * comp[c].bh * 8, 0);
+                comp[c].pred = 0;
+                if (!dc[comp[c].td].present || !ac[comp[c].ta].present) return "JPEG: missing Huffman table";
+            }
+            JpegReader rd{f.data() + seg_end, f.data() + f.size()};
+            int mcu_count = 0, next_rst = 0;
+            for (int my = 0; my < mcuy; ++my) {
+                for (int mx = 0; mx < mcux; ++mx) {
+                    if (restart_interval && mcu_count && mcu_count % restart_interval == 0) {
+                        // byte-align and consume the RSTn marker
+                        rd.reset_bits();
+                        while (rd.p + 1 < rd.end && !(rd.p[0] == 0xFF && rd.p[1] >= 0xD0 && rd.p[1] <= 0xD7)) ++rd.p;
+                        if (rd.p + 1 < rd.end) rd.p += 2;
+                        next_rst = (next_rst + 1) & 7;
+                        for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
+                    }
+                    for (int c = 0; c < ncomp; ++c) {
+                        for (int by = 0; by < comp[c].v; ++by) {
+                            for (int bx = 0; bx < comp[c].h; ++bx) {
+                                int coef[64] = {0};
+                                int s = rd.decode(dc[comp[c].td]);
+                                if (s < 0 || s > 15) return "JPEG: bad DC code";
+                                int diff = s ? extend(rd.get_bits(s), s) : 0;
+                                comp[c].pred += diff;
+                                coef[0] = comp[c].pred;
+                                for (int k = 1; k < 64;) {
+                                    int rs = rd.decode(ac[comp[c].ta]);
+                                    if (rs < 0) return "JPEG: bad AC code";
+                                    int r = rs >> 4, sz = rs & 15;
+                                    if (sz == 0) {
+                                        if (r == 15) { k += 16; continue; }
+                                        break;
+                                    }
+                                    k += r;
+                                    if (k > 63) return "JPEG: coefficient index out of range";
+                                    coef[kZigzag[k]] = extend(rd.get_bits(sz), sz);
+                                    ++k;
+                                }
+                                int px0 = (mx * comp[c].h + bx) * 8, py0 = (my * comp[c].v + by) * 8;
+                                int stride = comp[c].bw * 8;
+                                idct_block(coef, quant[comp[c].tq], &comp[c].plane[(size_t)py0 * stride + px0], stride);
+                            }
+                        }
+                    }
+                    ++mcu_count;
+                }
+            }
+            // assemble
+            *w = (uint32_t)width;
+            *h = (uint32_t)height;
+            *channels = ncomp == 1 ? 1u : 3u;
+            px->resize((size_t)width * height * *channels);
+            if (ncomp == 1) {
+                int stride = comp[0].bw * 8;
+                for (int y = 0; y < height; ++y) std::memcpy(&(*px)[(size_t)y * width], &comp[0].plane[(size_t)y * stride], (size_t)width);
+            } else {
+                for (int y = 0; y < height; ++y) {
+                    for (int x = 0; x < width; ++x) {
+                        int s[3];
+                        for (int c = 0; c < 3; ++c) {
+                            int sx = x * comp[c].h / hmax, sy = y * comp[c].v / vmax;
+                            s[c] = comp[c].plane[(size_t)sy * comp[c].bw * 8 + sx];
+                        }
+                        int Y = s[0], cb = s[1] - 128, cr = s[2] - 128;
+                        int r = Y + (int)((91881L * cr + 32768) >> 16);
+                        int g = Y + (int)((-22554L * cb + 32768 + -46802L * cr) >> 16);
+                        int b = Y + (int)((116130L * cb + 32768) >> 16);
+                        uint8_t* q = &(*px)[((size_t)y * width + x) * 3];
+                        q[0] = clamp8(r);
+                        q[1] = clamp8(g);
+                        q[2] = clamp8(b);
+                    }
+                }
+            }
+            return "";
+        }
+        i = seg_end;
+    }
+    return "JPEG: no image data found";
+}
+
+std::string decode_png(const std::vector<uint8_t>& f, uint32_t* w, uint32_t* h, uint32_t* channels, std::vector<uint8_t>* px) {
+    auto be32 = [&](size_t at) { return ((uint32_t)f[at] << 24) | ((uint32_t)f[at + 1] << 16) | ((uint32_t)f[at + 2] << 8) | (uint32_t)f[at + 3]; };
+    size_t i = 8;
+    uint32_t width = 0, height = 0;
+    int depth = 0, ctype = 0, interlace = 0;
+    std::vector<uint8_t> idat, palette;
+    while (i + 12 <= f.size()) {
+        uint32_t len = be32(i);
+        if (i + 12 + (size_t)len > f.size()) return "PNG: truncated chunk";
+        const uint8_t* tag = &f[i + 4];
+        const uint8_t* data = &f[i + 8];
+        if (!std::memcmp(tag, "IHDR", 4)) {
+            if (len < 13) return "PNG: bad IHDR";
+            width = be32(i + 8);
+            height = be32(i + 12);
+            depth = data[8];
+            ctype = data[9];
+            interlace = data[12];
+        } else if (!std::memcmp(tag, "PLTE", 4)) {
+            palette.assign(data, data + len);
+        } else if (!std::memcmp(tag, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!std::memcmp(tag, "IEND", 4)) {
+            break;
+        }
+        i += 12 + (size_t)len;
+    }
+    if (width == 0 || height == 0) return "PNG: missing IHDR";
+    if (interlace) return "PNG: interlaced files are not supported";
+    int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
+    if (!samples || (depth != 8 && depth != 16 && !((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))))
+        return "PNG: unsupported colour type / bit depth";
+    size_t bpp_bits = (size_t)samples * depth;
+    size_t row_bytes = (width * bpp_bits + 7) / 8;
+    size_t bpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;
+    std::vector<uint8_t> raw((row_bytes + 1) * height);
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return "PNG: inflate failed";
+    std::vector<uint8_t> prev(row_bytes, 0), cur(row_bytes);
+    *w = width;
+    *h = height;
+    *channels = (ctype == 0 || ctype == 4) ? 1u : 3u;
+    px->assign((size_t)width * height * *channels, 0);
+    for (uint32_t y = 0; y < height; ++y) {
+        const uint8_t* line = &raw[(row_bytes + 1) * y];
+        int filter = line[0];
+        for (size_t k = 0; k < row_bytes; ++k) {
+            int a = k >= bpp ? cur[k - bpp] : 0, b = prev[k], c = k >= bpp ? prev[k - bpp] : 0;
+            int x = line[1 + k];
+            switch (filter) {
+                case 0: break;
+                case 1: x += a; break;
+                case 2: x += b; break;
+                case 3: x += (a + b) >> 1; break;
+                case 4: {
+                    int p = a + b - c, pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
+                    x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                    break;
+                }
+                default: return "PNG: bad filter";
+            }
+            cur[k] = (uint8_t)x;
+        }
+        for (uint32_t x = 0; x < width; ++x) {
+            uint8_t s[4] = {0, 0, 0, 0};
+            for (int c = 0; c < samples; ++c) {
+                if (depth == 8) s[c] = cur[(size_t)x * samples + c];
+                else if (depth == 16) s[c] = cur[((size_t)x * samples + c) * 2];
+                else {
+                    size_t bit = (size_t)x * depth;
+                    int v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+                    s[c] = ctype == 3 ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1));
+                }
+            }
+            uint8_t* q = &(*px)[((size_t)y * width + x) * *channels];
+            if (ctype == 3) {
+                size_t pi = (size_t)s[0] * 3;
+                if (pi + 2 >= palette.size() + 0 && pi + 3 > palette.size()) return "PNG: palette index out of range";
+                q[0] = palette[pi]; q[1] = palette[pi + 1]; q[2] = palette[pi + 2];
+            } else if (*channels == 1) {
+                q[0] = s[0];
+            } else {
+                q[0] = s[0]; q[1] = s[1]; q[2] = s[2];
+            }
+        }
+        prev.swap(cur);
+    }
+    return "";
+}
+
+}  // namespace rrt_host

@@ -1,0 +1,799 @@
+// Device-side building blocks of the path tracer (gfx950).  Everything here is plain IEEE f32,
+// compiled with -ffp-contract=off: the reference (Rust) never fuses a*b+c, and hit/miss decisions
+// are only reproducible bit for bit with the same unfused operations in the same operand order.
+// Each function names the reference code it computes (paths relative to the reference root).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rrt.h"
+
+#define RRT_DEV __device__ __forceinline__
+
+namespace rrt {
+
+// ---- 3-vectors (vector.rs:57-79, base.rs:29-128) ------------------------------------------------
+struct f3 {
+    float x, y, z;
+};
+RRT_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+RRT_DEV f3 xyz(const float4& q) { return f3{q.x, q.y, q.z}; }
+RRT_DEV f3 ld3(const float* p) { return f3{p[0], p[1], p[2]}; }
+RRT_DEV f3 operator+(f3 a, f3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+RRT_DEV f3 operator-(f3 a, f3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+RRT_DEV f3 operator-(f3 a) { return mk3(-a.x, -a.y, -a.z); }
+RRT_DEV f3 operator*(f3 a, f3 b) { return mk3(a.x * b.x, a.y * b.y, a.z * b.z); }
+RRT_DEV f3 operator*(f3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+RRT_DEV f3 operator*(float s, f3 a) { return mk3(s * a.x, s * a.y, s * a.z); }
+RRT_DEV f3 operator/(f3 a, float s) { return mk3(a.x / s, a.y / s, a.z / s); }
+RRT_DEV float dot3(f3 a, f3 b) { return (a.x * b.x) + (a.y * b.y) + (a.z * b.z); }
+RRT_DEV float sqlen3(f3 a) { return (a.x * a.x) + (a.y * a.y) + (a.z * a.z); }
+RRT_DEV float len3(f3 a) { return __builtin_sqrtf(sqlen3(a)); }
+RRT_DEV f3 norm3(f3 a) { return a / len3(a); }
+RRT_DEV f3 cross3(f3 a, f3 b) { return mk3((a.y * b.z) - (a.z * b.y), (a.z * b.x) - (a.x * b.z), (a.x * b.y) - (a.y * b.x)); }
+
+#define RRT_PI 3.14159265358979323846f
+#define RRT_FRAC_PI_2 1.57079632679489661923f
+#define RRT_FRAC_1_PI 0.318309886183790671538f
+#define RRT_EPS 1.1920929e-7f
+#define RRT_T_MIN 0.001f
+#define RRT_T_MAX 3.402823466e+38f
+
+RRT_DEV float clampf(float v, float lo, float hi) { return v > hi ? hi : (v < lo ? lo : v); }  // utils.rs:51-59
+RRT_DEV float fmax_ref(float f, float m) { return f > m ? f : m; }                             // utils.rs:61-67
+RRT_DEV float fmin_ref(float f, float m) { return f < m ? f : m; }                             // utils.rs:69-75
+RRT_DEV float lerpf(float t, float a, float b) { return (1.0f - t) * a + t * b; }              // utils.rs:77-79
+
+// ---- deterministic elementary functions --------------------------------------------------------
+// sin/cos/asin/atan2/log built from single correctly-rounded f32 operations only, so the device and
+// any IEEE host produce identical bits (the platform libm / OCML versions differ in the last ulp).
+RRT_DEV void det_sincos(float x, float* s_out, float* c_out) {
+    const float two_over_pi = 0.63661977236758134308f;
+    const float c1 = 1.5703125f;
+    const float c2 = 4.837512969970703125e-4f;
+    const float c3 = 7.54978995489188e-8f;
+    float k = __builtin_floorf(x * two_over_pi + 0.5f);
+    float r = ((x - k * c1) - k * c2) - k * c3;
+    float r2 = r * r;
+    float sp = -1.9841270114e-4f + r2 * 2.7557314297e-6f;
+    sp = 8.3333337680e-3f + r2 * sp;
+    sp = -1.6666667163e-1f + r2 * sp;
+    float sr = r + (r * r2) * sp;
+    float cp = -1.3888889225e-3f + r2 * 2.4801587642e-5f;
+    cp = 4.1666667908e-2f + r2 * cp;
+    float cr = (1.0f - 0.5f * r2) + (r2 * r2) * cp;
+    float q = k - 4.0f * __builtin_floorf(k * 0.25f);
+    float s, c;
+    if (q == 0.0f) { s = sr; c = cr; }
+    else if (q == 1.0f) { s = cr; c = -sr; }
+    else if (q == 2.0f) { s = -sr; c = -cr; }
+    else { s = -cr; c = sr; }
+    *s_out = s;
+    *c_out = c;
+}
+RRT_DEV float det_sin(float x) { float s, c; det_sincos(x, &s, &c); return s; }
+RRT_DEV float det_cos(float x) { float s, c; det_sincos(x, &s, &c); return c; }
+RRT_DEV float det_atan_poly(float a) {
+    float z = a * a;
+    float p = 8.05374449538e-2f * z - 1.38776856032e-1f;
+    p = p * z + 1.99777106478e-1f;
+    p = p * z - 3.33329491539e-1f;
+    return a + (a * z) * p;
+}
+RRT_DEV float det_atan2(float y, float x) {
+    float ax = x < 0.0f ? -x : x;
+    float ay = y < 0.0f ? -y : y;
+    float hi = ax > ay ? ax : ay;
+    float lo = ax > ay ? ay : ax;
+    float r;
+    if (hi == 0.0f) {
+        r = 0.0f;
+    } else {
+        float a = lo / hi;
+        if (a > 0.4142135623730950f) r = 0.785398163397448309616f + det_atan_poly((a - 1.0f) / (a + 1.0f));
+        else r = det_atan_poly(a);
+    }
+    if (ay > ax) r = 1.57079632679489661923f - r;
+    if (x < 0.0f) r = 3.14159265358979323846f - r;
+    if (y < 0.0f) r = -r;
+    return r;
+}
+RRT_DEV float det_asin_poly(float z) {
+    float p = 4.2163199048e-2f * z + 2.4181311049e-2f;
+    p = p * z + 4.5470025998e-2f;
+    p = p * z + 7.4953002686e-2f;
+    p = p * z + 1.6666752422e-1f;
+    return p;
+}
+RRT_DEV float det_asin(float x) {
+    float a = x < 0.0f ? -x : x;
+    float r;
+    if (a > 1.0f) {
+        r = __builtin_nanf("");
+    } else if (a > 0.5f) {
+        float z = 0.5f * (1.0f - a);
+        float s = __builtin_sqrtf(z);
+        float as = s + (s * z) * det_asin_poly(z);
+        r = 1.57079632679489661923f - 2.0f * as;
+    } else {
+        float z = a * a;
+        r = a + (a * z) * det_asin_poly(z);
+    }
+    return x < 0.0f ? -r : r;
+}
+RRT_DEV float det_log(float x) {
+    if (x < 0.0f) return __builtin_nanf("");
+    if (x == 0.0f) return -__builtin_inff();
+    uint32_t bits = __float_as_uint(x);
+    int e = (int)((bits >> 23) & 0xffu) - 127;
+    float m = __uint_as_float((bits & 0x007fffffu) | 0x3f800000u);
+    if (m > 1.41421356237f) {
+        m = m * 0.5f;
+        e = e + 1;
+    }
+    float s = (m - 1.0f) / (m + 1.0f);
+    float s2 = s * s;
+    float p = 0.2222222222f + s2 * 0.1818181818f;
+    p = 0.2857142857f + s2 * p;
+    p = 0.4f + s2 * p;
+    p = 0.6666666667f + s2 * p;
+    float lm = 2.0f * s + (s * s2) * p;
+    float fe = (float)e;
+    return (fe * 0.693359375f + (fe * -2.12194440054690583e-4f)) + lm;
+}
+
+// ---- per-path random stream ----------------------------------------------------------------------
+// Stands in for rand::random::<f32>() (rand 0.7.3, unseedable in the reference): xoroshiro64* seeded
+// by a hash of (seed, pixel, sample); f32 = top 24 bits * 2^-24, the crate's Standard distribution.
+RRT_DEV uint32_t mix32(uint32_t x) {
+    x ^= x >> 16;
+    x *= 0x7feb352du;
+    x ^= x >> 15;
+    x *= 0x846ca68bu;
+    x ^= x >> 16;
+    return x;
+}
+RRT_DEV uint32_t rotl32(uint32_t x, int k) { return (x << k) | (x >> (32 - k)); }
+struct Rng {
+    uint32_t s0, s1;
+};
+RRT_DEV Rng rng_seed(uint32_t seed, uint32_t pixel, uint32_t sample) {
+    uint32_t a = mix32(pixel ^ mix32(seed));
+    uint32_t b = mix32(sample ^ 0x5bd1e995u);
+    Rng r;
+    r.s0 = mix32(a + b);
+    r.s1 = mix32(b ^ r.s0);
+    if ((r.s0 | r.s1) == 0u) r.s1 = 0x9e3779b9u;
+    return r;
+}
+RRT_DEV uint32_t rng_u32(Rng& r) {
+    uint32_t s0 = r.s0, s1 = r.s1;
+    uint32_t out = s0 * 0x9e3779bbu;
+    s1 ^= s0;
+    r.s0 = rotl32(s0, 26) ^ s1 ^ (s1 << 9);
+    r.s1 = rotl32(s1, 13);
+    return out;
+}
+RRT_DEV float u32_to_unit(uint32_t u) { return (float)(u >> 8) * (1.0f / 16777216.0f); }
+RRT_DEV float rng_f32(Rng& r) { return u32_to_unit(rng_u32(r)); }
+RRT_DEV uint32_t rng_index(Rng& r, uint32_t n) { return __umulhi(rng_u32(r), n); }  // SliceRandom::choose, pdf.rs:110
+// The draw of ConstantMedium::hit (volume.rs:95) is keyed by (stream state, depth, primitive) so that it
+// does not depend on which other BVH nodes were visited before.
+RRT_DEV float rng_keyed(const Rng& r, uint32_t depth, uint32_t prim) {
+    uint32_t h = mix32(r.s1 + depth * 0x9e3779b9u + prim * 0x85ebca6bu);
+    return u32_to_unit(mix32(r.s0 ^ h));
+}
+
+// ---- device view of the scene ----------------------------------------------------------------------
+struct DScene {
+    const float4* nodes;      // 2 x float4 per rrt_node
+    const float4* slots;      // 3 x float4 per rrt_slot
+    const float4* tri_shade;  // 3 x float4 per rrt_tri_shade
+    const rrt_sphere* spheres;
+    const rrt_medium* media;
+    const float4* btris;
+    const float4* btri_shade;
+    const rrt_material* materials;
+    const rrt_texture* textures;
+    const uint8_t* texels;
+    const rrt_light* lights;
+    uint32_t n_nodes, n_slots, n_lights, is_list;
+    rrt_camera cam;
+};
+
+struct Ray {
+    f3 o, d;
+};
+RRT_DEV f3 point_at(const Ray& r, float t) { return r.o + (r.d * t); }  // ray.rs:17-19
+
+// ---- samplers (utils.rs:10-49) and the orthonormal basis (utils.rs:191-214) ---------------------------
+RRT_DEV f3 random_unit_disk(Rng& g) {
+    float x = 2.0f * rng_f32(g) - 1.0f;
+    float y = __builtin_sqrtf(1.0f - x * x);
+    return mk3(x, y, 0.0f);
+}
+RRT_DEV f3 unit_sphere_random(Rng& g) {
+    float azimuth = rng_f32(g) * RRT_PI * 2.0f;
+    float y = rng_f32(g);
+    float sin_elevation = __builtin_sqrtf(1.0f - y * y);
+    float sa, ca;
+    det_sincos(azimuth, &sa, &ca);
+    return mk3(sin_elevation * ca, y, sin_elevation * sa);
+}
+RRT_DEV f3 random_cosine_direction(Rng& g) {
+    float r1 = rng_f32(g);
+    float r2 = rng_f32(g);
+    float z = __builtin_sqrtf(1.0f - r2);
+    float phi = 2.0f * RRT_PI * r1;
+    float sp, cp;
+    det_sincos(phi, &sp, &cp);
+    float x = cp * __builtin_sqrtf(r2);
+    float y = sp * __builtin_sqrtf(r2);
+    return mk3(x, y, z);
+}
+RRT_DEV f3 random_to_sphere(Rng& g, float radius, float distance_squared) {
+    float r1 = rng_f32(g);
+    float r2 = rng_f32(g);
+    float z = 1.0f + r2 * (__builtin_sqrtf(fmax_ref(1.0f - radius * radius / distance_squared, 0.0f)) - 1.0f);
+    float phi = 2.0f * RRT_PI * r1;
+    float sp, cp;
+    det_sincos(phi, &sp, &cp);
+    float x = cp * __builtin_sqrtf(fmax_ref(1.0f - z * z, 0.0f));
+    float y = sp * __builtin_sqrtf(fmax_ref(1.0f - z * z, 0.0f));
+    return mk3(x, y, z);
+}
+// OrthonormalBasis::new(v).local(d); v is used as given (not normalised), as the reference does.
+RRT_DEV f3 onb_local(f3 v, f3 d) {
+    f3 a = __builtin_fabsf(v.x) > 0.9f ? mk3(0.0f, 1.0f, 0.0f) : mk3(1.0f, 0.0f, 0.0f);
+    f3 axis1 = norm3(cross3(v, a));
+    f3 axis0 = cross3(v, axis1);
+    return (d.x * axis0) + (d.y * axis1) + (d.z * v);
+}
+
+// ---- Perlin noise (utils.rs:82-189) ----------------------------------------------------------------------
+__device__ const uint8_t k_noise_perm[256] = {
+    63, 147, 186, 78, 92, 53, 229, 76, 14, 204, 183, 99, 237, 241, 59, 167, 118, 23, 29, 44, 82,
+    37, 6, 249, 131, 253, 210, 28, 71, 96, 3, 207, 115, 32, 158, 61, 215, 220, 116, 40, 48, 93,
+    179, 196, 141, 0, 165, 185, 145, 217, 139, 216, 250, 235, 39, 232, 124, 146, 5, 77, 180, 4, 31,
+    203, 154, 178, 226, 25, 20, 130, 22, 240, 252, 163, 75, 90, 51, 89, 151, 193, 33, 69, 21, 149,
+    208, 244, 238, 191, 161, 36, 38, 81, 181, 56, 43, 127, 34, 243, 65, 200, 97, 247, 79, 231, 98,
+    11, 100, 142, 15, 166, 45, 209, 223, 66, 119, 155, 49, 153, 113, 41, 133, 197, 157, 112, 46,
+    91, 74, 27, 128, 228, 16, 248, 174, 187, 87, 95, 30, 110, 212, 175, 144, 135, 225, 172, 221,
+    170, 67, 9, 111, 224, 239, 176, 117, 109, 177, 202, 132, 80, 125, 62, 251, 108, 148, 103, 227,
+    50, 17, 35, 24, 126, 164, 42, 156, 10, 182, 218, 70, 246, 150, 73, 213, 138, 129, 189, 188, 84,
+    160, 134, 105, 83, 169, 121, 233, 194, 19, 114, 55, 211, 58, 104, 254, 57, 18, 123, 102, 140,
+    8, 171, 68, 206, 168, 86, 136, 152, 47, 60, 88, 101, 26, 122, 13, 192, 94, 198, 64, 234, 195,
+    52, 245, 54, 236, 219, 12, 106, 143, 120, 7, 190, 1, 2, 205, 222, 159, 162, 173, 85, 107, 201,
+    184, 214, 137, 230, 255, 242, 72, 199};
+RRT_DEV int perm_at(int i) { return (int)k_noise_perm[i & 255]; }  // the reference's 512-entry table is this one twice
+RRT_DEV int f32_to_i32_sat(float f) {  // Rust `as i32`
+    if (f != f) return 0;
+    if (f >= 2147483648.0f) return 2147483647;
+    if (f <= -2147483648.0f) return (-2147483647 - 1);
+    return (int)f;
+}
+RRT_DEV uint32_t f32_to_u32_sat(float f) {  // Rust `as u32`
+    if (f != f) return 0u;
+    if (f <= 0.0f) return 0u;
+    if (f >= 4294967296.0f) return 0xffffffffu;
+    return (uint32_t)f;
+}
+RRT_DEV float perlin_gradient(int x, int y, int z, float dx, float dy, float dz) {  // utils.rs:149-170
+    int val = perm_at(perm_at(perm_at(x) + y) + z) & 15;
+    float u = (val < 8 || val == 12 || val == 13) ? dx : dy;
+    float v = (val < 4 || val == 12 || val == 13) ? dy : dz;
+    if ((val & 1) > 0) u = -u;
+    if ((val & 2) > 0) v = -v;
+    return u + v;
+}
+RRT_DEV float perlin_smooth(float f) {  // utils.rs:171-175
+    float f_3 = f * f * f;
+    float f_4 = f_3 * f;
+    return 6.0f * f_4 * f - 15.0f * f_4 + 10.0f * f_3;
+}
+RRT_DEV float perlin_noise(f3 p) {  // utils.rs:112-148
+    int ix = f32_to_i32_sat(__builtin_floorf(p.x));
+    int iy = f32_to_i32_sat(__builtin_floorf(p.y));
+    int iz = f32_to_i32_sat(__builtin_floorf(p.z));
+    float dx = p.x - (float)ix, dy = p.y - (float)iy, dz = p.z - (float)iz;
+    ix &= 255; iy &= 255; iz &= 255;
+    float w000 = perlin_gradient(ix, iy, iz, dx, dy, dz);
+    float w100 = perlin_gradient(ix + 1, iy, iz, dx - 1.0f, dy, dz);
+    float w010 = perlin_gradient(ix, iy + 1, iz, dx, dy - 1.0f, dz);
+    float w001 = perlin_gradient(ix, iy, iz + 1, dx, dy, dz - 1.0f);
+    float w110 = perlin_gradient(ix + 1, iy + 1, iz, dx - 1.0f, dy - 1.0f, dz);
+    float w101 = perlin_gradient(ix + 1, iy, iz + 1, dx - 1.0f, dy, dz - 1.0f);
+    float w011 = perlin_gradient(ix, iy + 1, iz + 1, dx, dy - 1.0f, dz - 1.0f);
+    float w111 = perlin_gradient(ix + 1, iy + 1, iz + 1, dx - 1.0f, dy - 1.0f, dz - 1.0f);
+    float wx = perlin_smooth(dx), wy = perlin_smooth(dy), wz = perlin_smooth(dz);
+    float x00 = lerpf(wx, w000, w100);
+    float x10 = lerpf(wx, w010, w110);
+    float x01 = lerpf(wx, w001, w101);
+    float x11 = lerpf(wx, w011, w111);
+    float y0 = lerpf(wy, x00, x10);
+    float y1 = lerpf(wy, x01, x11);
+    return lerpf(wz, y0, y1);
+}
+RRT_DEV float perlin_turbulence(f3 p, uint32_t depth, float omega) {  // utils.rs:177-189
+    float sum = 0.0f;
+    float weight = 1.0f;
+    for (uint32_t i = 0; i < depth; ++i) {
+        sum += weight * perlin_noise(p);
+        weight *= omega;
+        p = p * 1.99f;
+    }
+    return __builtin_fabsf(sum);
+}
+
+// ---- textures (texture.rs:61-179) ------------------------------------------------------------------------
+RRT_DEV f3 texture_value(const DScene& sc, int tex, float u, float v, f3 p) {
+    for (;;) {
+        const rrt_texture t = sc.textures[tex];
+        switch (t.type) {
+            case RRT_TEX_CONSTANT:
+                return mk3(t.a, t.b, t.c);
+            case RRT_TEX_TEST: {
+                float w = 1.0f - u - v;
+                return mk3(u, v, w < 0.0f ? 0.0f : w);
+            }
+            case RRT_TEX_CHECKER: {
+                float sines = det_sin(t.a * p.x) * det_sin(t.a * p.y) * det_sin(t.a * p.z);
+                tex = sines < 0.0f ? (int)t.u0 : (int)t.u1;
+                continue;
+            }
+            case RRT_TEX_IMAGE: {
+                uint32_t i = f32_to_u32_sat(u * (float)t.u0) % t.u0;
+                uint32_t j = f32_to_u32_sat((1.0f - v) * (float)t.u1) % t.u1;
+                const uint8_t* px = sc.texels + t.u3 + ((size_t)j * t.u0 + i) * t.u2;
+                uint8_t r = px[0];
+                uint8_t g = t.u2 >= 3 ? px[1] : r;
+                uint8_t b = t.u2 >= 3 ? px[2] : r;
+                f3 c = mk3((float)r / 255.0f, (float)g / 255.0f, (float)b / 255.0f);
+                return c * c;  // color.rs:41-43
+            }
+            case RRT_TEX_NOISE:
+                return mk3(0.5f, 0.5f, 0.5f) * (1.0f + perlin_noise(p * t.a));
+            default:  // RRT_TEX_TURBULENCE
+                return mk3(1.0f, 1.0f, 1.0f) * perlin_turbulence(p * t.a, t.u0, t.b);
+        }
+    }
+}
+RRT_DEV float texture_bump_value(const DScene& sc, int tex, float u, float v, f3 p) {  // texture.rs:63-66
+    f3 b = texture_value(sc, tex, u, v, p);
+    return (b.x + b.y + b.z) / 3.0f;
+}
+
+// ---- primitives ----------------------------------------------------------------------------------------------
+// Triangle::hit (shape.rs:335-372) on a slot holding v0, e1 = v1 - v0, e2 = v2 - v0.
+RRT_DEV bool triangle_hit(f3 v0, f3 e1, f3 e2, bool cull, const Ray& r, float t_min, float t_max, float* t_out) {
+    f3 p_vec = cross3(r.d, e2);
+    float det = dot3(e1, p_vec);
+    if (!cull && det > -RRT_EPS && det < RRT_EPS) return false;
+    else if (cull && det < RRT_EPS) return false;
+    float inv_det = 1.0f / det;
+    f3 t_vec = r.o - v0;
+    float u = dot3(t_vec, p_vec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 q_vec = cross3(t_vec, e1);
+    float v = dot3(r.d, q_vec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t_hit = dot3(e2, q_vec) * inv_det;
+    if (t_hit < t_max && t_hit > t_min) {
+        *t_out = t_hit;
+        return true;
+    }
+    return false;
+}
+// &Matrix4 * &Ray (matrix.rs:154-190) with a row-major 3x4
+RRT_DEV Ray xform_ray(const float* m, const Ray& r) {
+    Ray o;
+    o.o = mk3(m[0] * r.o.x + m[1] * r.o.y + m[2] * r.o.z + m[3] * 1.0f, m[4] * r.o.x + m[5] * r.o.y + m[6] * r.o.z + m[7] * 1.0f,
+              m[8] * r.o.x + m[9] * r.o.y + m[10] * r.o.z + m[11] * 1.0f);
+    o.d = mk3(m[0] * r.d.x + m[1] * r.d.y + m[2] * r.d.z, m[4] * r.d.x + m[5] * r.d.y + m[6] * r.d.z,
+              m[8] * r.d.x + m[9] * r.d.y + m[10] * r.d.z);
+    return o;
+}
+RRT_DEV f3 xform_vec(const float* m, f3 v) {
+    return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+RRT_DEV f3 xform_point(const float* m, f3 p) {
+    return mk3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3] * 1.0f, m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7] * 1.0f,
+               m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * 1.0f);
+}
+// Sphere::hit (shape.rs:65-85)
+RRT_DEV bool sphere_hit(const rrt_sphere& s, const Ray& r, float t_min, float t_max, float* t_out) {
+    Ray lr = xform_ray(s.w2l, r);
+    f3 oc = lr.o - mk3(0.0f, 0.0f, 0.0f);
+    float a = dot3(lr.d, lr.d);
+    float b = 2.0f * dot3(oc, lr.d);
+    float c = dot3(oc, oc) - (s.radius * s.radius);
+    float disc = b * b - 4.0f * a * c;
+    if (disc > 0.0f) {
+        float t_hit = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
+        if (t_hit >= t_max || t_hit <= t_min) t_hit = (-b + __builtin_sqrtf(disc)) / (2.0f * a);
+        if (t_hit < t_max && t_hit > t_min) {
+            *t_out = t_hit;
+            return true;
+        }
+    }
+    return false;
+}
+// The boundary shape of a medium: a sphere or a single triangle.
+RRT_DEV bool boundary_hit(const DScene& sc, const rrt_medium& m, const Ray& r, float t_min, float t_max, float* t_out) {
+    if (m.boundary_kind == RRT_KIND_SPHERE) return sphere_hit(sc.spheres[m.boundary_index], r, t_min, t_max, t_out);
+    float4 q0 = sc.btris[3 * m.boundary_index], q1 = sc.btris[3 * m.boundary_index + 1], q2 = sc.btris[3 * m.boundary_index + 2];
+    return triangle_hit(xyz(q0), xyz(q1), xyz(q2), (__float_as_uint(q1.w) & RRT_INFO_CULL) != 0, r, t_min, t_max, t_out);
+}
+// ConstantMedium::hit (volume.rs:65-102); xi is the uniform draw of line 95
+RRT_DEV bool medium_hit(const DScene& sc, const rrt_medium& m, const Ray& r, float t_min, float t_max, float xi, float* t_out) {
+    float t1, t2;
+    if (!boundary_hit(sc, m, r, -RRT_T_MAX, RRT_T_MAX, &t1)) return false;
+    if (!boundary_hit(sc, m, r, t1 + RRT_EPS, RRT_T_MAX, &t2)) return false;
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return false;
+    if (t1 < 0.0f) t1 = 0.0f;
+    float distance_inside = (t2 - t1) * len3(r.d);
+    float hit_dist = (-1.0f / m.density) * det_log(xi);
+    if (hit_dist > distance_inside) return false;
+    *t_out = t1 + (hit_dist / len3(r.d));
+    return true;
+}
+
+// ---- bounding boxes (aggregate.rs:471-503) ---------------------------------------------------------------------
+RRT_DEV void slab(float lo, float hi, float o, float inv, float* t0, float* t1) {
+    float a = (lo - o) * inv;
+    float b = (hi - o) * inv;
+    bool neg = inv < 0.0f;
+    *t0 = neg ? b : a;
+    *t1 = neg ? a : b;
+}
+// The reference's test, verbatim: an exit is honoured only against the ENTRY bound (`t1 < t_min`).
+RRT_DEV bool aabb_reference(f3 bmin, f3 bmax, f3 o, f3 inv, float t_min, float t_max) {
+    float t0, t1;
+    slab(bmin.x, bmax.x, o.x, inv.x, &t0, &t1);
+    float lo = t0 > t_min ? t0 : t_min;
+    float hi = t1 < t_min ? t1 : t_max;
+    if (hi <= lo) return false;
+    slab(bmin.y, bmax.y, o.y, inv.y, &t0, &t1);
+    float lo2 = t0 > lo ? t0 : lo;
+    float hi2 = t1 < lo ? t1 : hi;
+    if (hi2 <= lo2) return false;
+    slab(bmin.z, bmax.z, o.z, inv.z, &t0, &t1);
+    float lo3 = t0 > lo2 ? t0 : lo2;
+    float hi3 = t1 < lo2 ? t1 : hi2;
+    if (hi3 <= lo3) return false;
+    return true;
+}
+// Complete slab test.  Accepts every box the reference's test accepts AND the segment can actually reach:
+// it rejects a box only when its entry is at/after t_max (as the reference does) or when its exit precedes its
+// entry by more than a 1e-5 relative margin, so rounding can never cull a box whose primitive the reference hits.
+RRT_DEV bool aabb_tight(f3 bmin, f3 bmax, f3 o, f3 inv, float t_min, float t_max) {
+    float lo = t_min, hi = t_max, t0, t1;
+    slab(bmin.x, bmax.x, o.x, inv.x, &t0, &t1);
+    lo = t0 > lo ? t0 : lo;
+    hi = t1 < hi ? t1 : hi;
+    slab(bmin.y, bmax.y, o.y, inv.y, &t0, &t1);
+    lo = t0 > lo ? t0 : lo;
+    hi = t1 < hi ? t1 : hi;
+    slab(bmin.z, bmax.z, o.z, inv.z, &t0, &t1);
+    lo = t0 > lo ? t0 : lo;
+    hi = t1 < hi ? t1 : hi;
+    if (lo >= t_max) return false;
+    float hi_pad = hi + __builtin_fabsf(hi) * 1.0e-5f;
+    float lo_pad = lo - __builtin_fabsf(lo) * 1.0e-5f;
+    return hi_pad >= lo_pad;
+}
+
+// ---- closest hit: BVH::hit (aggregate.rs:324-401) with List::hit (aggregate.rs:144-165) in the leaves ------------
+struct Hit {
+    int slot;  // -1 = miss
+    float t;
+};
+// `stack` points at this lane's first entry of an LDS array laid out [entry][thread]; `stride` = threads per block.
+template <int AABB_MODE>
+RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack, uint32_t stride) {
+    Hit h;
+    h.slot = -1;
+    h.t = t_max;
+    if (sc.n_nodes == 0) return h;
+    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    uint32_t sp = 0;
+    uint32_t cur = 0;
+    for (;;) {
+        const float4 n0 = sc.nodes[2 * cur];
+        const float4 n1 = sc.nodes[2 * cur + 1];
+        bool inside;
+        if (sc.is_list) inside = true;
+        else if (AABB_MODE == RRT_AABB_REFERENCE) inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
+        else inside = aabb_tight(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
+        if (inside) {
+            const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
+            if (b & RRT_LEAF_FLAG) {
+                const uint32_t count = b & ~RRT_LEAF_FLAG;
+                for (uint32_t k = 0; k < count; ++k) {
+                    const uint32_t s = a + k;
+                    const float4 q0 = sc.slots[3 * s], q1 = sc.slots[3 * s + 1], q2 = sc.slots[3 * s + 2];
+                    const uint32_t info = __float_as_uint(q1.w);
+                    const uint32_t kind = RRT_INFO_KIND(info);
+                    float t;
+                    bool got;
+                    if (kind == RRT_KIND_TRIANGLE) {
+                        got = triangle_hit(xyz(q0), xyz(q1), xyz(q2), (info & RRT_INFO_CULL) != 0, r, t_min, h.t, &t);
+                    } else if (kind == RRT_KIND_SPHERE) {
+                        got = sphere_hit(sc.spheres[__float_as_uint(q2.w)], r, t_min, h.t, &t);
+                    } else {
+                        float xi = rng_keyed(key, depth, __float_as_uint(q0.w));
+                        got = medium_hit(sc, sc.media[__float_as_uint(q2.w)], r, t_min, h.t, xi, &t);
+                    }
+                    if (got) {
+                        h.t = t;
+                        h.slot = (int)s;
+                    }
+                }
+            } else {
+                // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
+                const float dax = b == 0u ? r.d.x : (b == 1u ? r.d.y : r.d.z);
+                const uint32_t left = cur + 1u, right = a;
+                const bool left_first = dax < 0.0f;
+                stack[sp * stride] = left_first ? right : left;
+                ++sp;
+                cur = left_first ? left : right;
+                continue;
+            }
+        }
+        if (sp == 0) break;
+        --sp;
+        cur = stack[sp * stride];
+    }
+    return h;
+}
+
+// ---- hit properties (shape.rs:87-123, 374-424) ---------------------------------------------------------------------
+struct HitProps {
+    f3 p, n;
+    float u, v;
+    f3 pu, pv;
+};
+RRT_DEV float signum_ref(float f) {  // f32::signum
+    if (f != f) return f;
+    return (__float_as_uint(f) >> 31) ? -1.0f : 1.0f;
+}
+RRT_DEV HitProps sphere_props(const rrt_sphere& s, const Ray& r, float t_hit, bool want_uv) {
+    const float one_over_2pi = 1.0f / (2.0f * RRT_PI);  // shape.rs:63
+    Ray lr = xform_ray(s.w2l, r);
+    f3 lp = point_at(lr, t_hit);
+    f3 hp = lp * (__builtin_fabsf(s.radius) / len3(lp - mk3(0.0f, 0.0f, 0.0f)));
+    HitProps h;
+    h.p = point_at(r, t_hit);
+    h.n = norm3(xform_vec(s.l2w, (lp - mk3(0.0f, 0.0f, 0.0f)) / s.radius));
+    if (want_uv) {  // uv, pu, pv feed textures and bump maps only
+        float theta = det_asin(clampf(hp.y / s.radius, -1.0f, 1.0f));
+        float inv_y_radius = (signum_ref(s.radius) * 1.0f) / __builtin_sqrtf(hp.x * hp.x + hp.z * hp.z);
+        f3 pu = mk3(2.0f * RRT_PI * hp.z, 0.0f, -2.0f * RRT_PI * hp.x);
+        f3 pv = (-RRT_PI) * mk3(hp.y * hp.x * inv_y_radius, (-s.radius) * det_cos(theta), hp.y * hp.z * inv_y_radius);
+        h.u = 1.0f - ((det_atan2(hp.z, hp.x) + RRT_PI) * one_over_2pi);
+        h.v = (theta + RRT_FRAC_PI_2) * RRT_FRAC_1_PI;
+        h.pu = xform_vec(s.l2w, pu);
+        h.pv = xform_vec(s.l2w, pv);
+    } else {
+        h.u = h.v = 0.0f;
+        h.pu = h.pv = mk3(0.0f, 0.0f, 0.0f);
+    }
+    return h;
+}
+RRT_DEV HitProps triangle_props(f3 v0, f3 e1, f3 e2, const float4& s0, const float4& s1, const float4& s2, const Ray& r, float t_hit) {
+    f3 p_vec = cross3(r.d, e2);
+    float det = dot3(e1, p_vec);
+    f3 normal = norm3(cross3(e1, e2));
+    if (det < 0.0f) normal = -normal;
+    float inv_det = 1.0f / det;
+    f3 t_vec = r.o - v0;
+    float u = dot3(t_vec, p_vec) * inv_det;
+    f3 q_vec = cross3(t_vec, e1);
+    float v = dot3(r.d, q_vec) * inv_det;
+    float w = 1.0f - u - v;
+    // tri_shade: s0 = (uv0.u, uv0.v, uv1.u, uv1.v), s1 = (uv2.u, uv2.v, pu.x, pu.y), s2 = (pu.z, pv.x, pv.y, pv.z)
+    HitProps h;
+    h.u = s0.x * u + s0.z * v + s1.x * w;  // uv0 pairs with u, uv1 with v, uv2 with w (shape.rs:407-410)
+    h.v = s0.y * u + s0.w * v + s1.y * w;
+    f3 pu = mk3(s1.z, s1.w, s2.x);
+    if (det < 0.0f) pu = -pu;
+    h.p = point_at(r, t_hit);
+    h.n = normal;
+    h.pu = pu;
+    h.pv = mk3(s2.y, s2.z, s2.w);
+    return h;
+}
+// Shape::get_hit_properties for whatever sits in `slot`; *material receives Shape::get_material.
+RRT_DEV HitProps slot_props(const DScene& sc, int slot, const Ray& r, float t_hit, uint32_t* material) {
+    const float4 q0 = sc.slots[3 * slot], q1 = sc.slots[3 * slot + 1], q2 = sc.slots[3 * slot + 2];
+    const uint32_t info = __float_as_uint(q1.w);
+    *material = RRT_INFO_MATERIAL(info);
+    const uint32_t kind = RRT_INFO_KIND(info);
+    if (kind == RRT_KIND_TRIANGLE) {
+        return triangle_props(xyz(q0), xyz(q1), xyz(q2), sc.tri_shade[3 * slot], sc.tri_shade[3 * slot + 1], sc.tri_shade[3 * slot + 2], r, t_hit);
+    }
+    if (kind == RRT_KIND_SPHERE) return sphere_props(sc.spheres[__float_as_uint(q2.w)], r, t_hit, true);
+    const rrt_medium m = sc.media[__float_as_uint(q2.w)];  // volume.rs:104-106
+    if (m.boundary_kind == RRT_KIND_SPHERE) return sphere_props(sc.spheres[m.boundary_index], r, t_hit, true);
+    const uint32_t bi = m.boundary_index;
+    return triangle_props(xyz(sc.btris[3 * bi]), xyz(sc.btris[3 * bi + 1]), xyz(sc.btris[3 * bi + 2]), sc.btri_shade[3 * bi],
+                          sc.btri_shade[3 * bi + 1], sc.btri_shade[3 * bi + 2], r, t_hit);
+}
+
+// ---- light mixture (pdf.rs:85-128; shape.rs:141-166, 441-471) -----------------------------------------------------------
+RRT_DEV float light_pdf(const DScene& sc, const rrt_light& l, const Ray& r) {
+    if (l.kind == RRT_KIND_SPHERE) {  // Sphere::pdf
+        const rrt_sphere& s = sc.spheres[l.index];
+        float t;
+        if (!sphere_hit(s, r, RRT_T_MIN, RRT_T_MAX, &t)) return 0.0f;
+        Ray lr = xform_ray(s.w2l, r);
+        float cos_theta_max = __builtin_sqrtf(fmax_ref(1.0f - s.radius * s.radius / sqlen3(mk3(0.0f, 0.0f, 0.0f) - lr.o), 0.0f));
+        float solid_angle = 2.0f * RRT_PI * (1.0f - cos_theta_max);
+        return 1.0f / solid_angle;
+    }
+    // Triangle::pdf
+    float t_hit;
+    if (!triangle_hit(ld3(l.v0), ld3(l.e1), ld3(l.e2), l.cull != 0, r, RRT_T_MIN, RRT_T_MAX, &t_hit)) return 0.0f;
+    float dist_squared = t_hit * t_hit * sqlen3(r.d);
+    // the hit normal is +-nrm; only |cos| is used, and negation is exact
+    float cosine = __builtin_fabsf(dot3(r.d, ld3(l.nrm)) / len3(r.d));
+    return dist_squared / (cosine * l.area);
+}
+RRT_DEV f3 light_sample(const DScene& sc, const rrt_light& l, f3 from, Rng& g) {
+    if (l.kind == RRT_KIND_SPHERE) {  // Sphere::random_dir_towards
+        const rrt_sphere& s = sc.spheres[l.index];
+        f3 local_point = xform_point(s.w2l, from);
+        f3 dir = mk3(0.0f, 0.0f, 0.0f) - local_point;
+        f3 d = random_to_sphere(g, s.radius, sqlen3(dir));
+        return xform_vec(s.l2w, onb_local(dir, d));
+    }
+    // Triangle::random_dir_towards
+    float r1 = rng_f32(g);
+    float r2 = rng_f32(g);
+    f3 random_point = ld3(l.v0) * (1.0f - __builtin_sqrtf(r1)) + ld3(l.v1) * (__builtin_sqrtf(r1) * (1.0f - r2)) + ld3(l.v2) * (r2 * __builtin_sqrtf(r1));
+    return random_point - from;
+}
+RRT_DEV float mixture_value(const DScene& sc, const Ray& r) {  // Mixture::value
+    float weight = 1.0f / (float)sc.n_lights;
+    float sum = 0.0f;
+    for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * light_pdf(sc, sc.lights[i], r);
+    return sum;
+}
+RRT_DEV float cosine_value(f3 normal, const Ray& r) {  // pdf.rs:51-58
+    float cosine = dot3(norm3(r.d), normal);
+    return cosine < 0.0f ? 0.0f : cosine / RRT_PI;
+}
+
+// ---- materials (material.rs:15-54) -----------------------------------------------------------------------------------------
+RRT_DEV f3 reflect_ref(f3 v, f3 n) { return v - 2.0f * dot3(v, n) * n; }
+RRT_DEV f3 refract_ref(f3 v, f3 n, float index) {
+    float cos_theta = dot3(-v, n);
+    f3 r_par = index * (v + cos_theta * n);
+    f3 r_perp = (-__builtin_sqrtf(1.0f - sqlen3(r_par))) * n;
+    return r_par + r_perp;
+}
+RRT_DEV float schlick_ref(float cosine, float index) {
+    float r0 = (1.0f - index) / (1.0f + index);
+    r0 = r0 * r0;
+    float a = 1.0f - cosine;
+    float a2 = a * a;
+    float a4 = a2 * a2;
+    return r0 + (1.0f - r0) * (a * a4);  // f32::powi(5) = a * ((a*a)*(a*a))
+}
+RRT_DEV f3 bump_normal(const DScene& sc, const HitProps& hp, int bump_tex) {
+    const float delta = 0.005f;
+    float d0 = texture_bump_value(sc, bump_tex, hp.u, hp.v, hp.p);
+    float du = texture_bump_value(sc, bump_tex, hp.u + delta, hp.v, hp.p + delta * hp.pu);
+    float dv = texture_bump_value(sc, bump_tex, hp.u, hp.v + delta, hp.p + delta * hp.pv);
+    f3 new_pu = hp.pu + ((du - d0) / delta) * hp.n;
+    f3 new_pv = hp.pv + ((dv - d0) / delta) * hp.n;
+    return norm3(cross3(new_pu, new_pv));
+}
+
+RRT_DEV f3 background(uint32_t bg, const Ray& r) {
+    if (bg == RRT_BG_BLACK) return mk3(0.0f, 0.0f, 0.0f);  // main.rs:268-270
+    f3 dn = norm3(r.d);                                    // main.rs:259-267
+    float t = 0.5f * (dn.y + 1.0f);
+    return mk3(1.0f, 1.0f, 1.0f) * (1.0f - t) + mk3(0.5f, 0.7f, 1.0f) * t;
+}
+
+// Camera::get_ray (camera.rs:53-63) for pixel (x, y) with the jitter of main.rs:227-228
+RRT_DEV Ray camera_ray(const rrt_camera& c, uint32_t x, uint32_t y, uint32_t W, uint32_t H, Rng& g) {
+    float u = ((float)x + rng_f32(g)) / (float)W;
+    float v = ((float)(H - y) + rng_f32(g)) / (float)H;
+    f3 disk = c.lens_radius * random_unit_disk(g);
+    f3 cu = ld3(c.u), cv = ld3(c.v);
+    f3 offset = cu * disk.x + cv * disk.y;
+    Ray r;
+    r.o = ld3(c.origin) + offset;
+    r.d = ld3(c.lower_left_corner) + (ld3(c.horizontal) * u) + (ld3(c.vertical) * v) - ld3(c.origin) - offset;
+    return r;
+}
+
+// One step of aggregate::trace (aggregate.rs:26-104) after the closest-hit query, in loop form: either the path ends
+// with a radiance value (`*radiance`, to be weighted by the throughput) or the ray and throughput are advanced.
+// Returns true when the path ended.
+RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, uint32_t depth, uint32_t max_depth, uint32_t bg, f3* radiance) {
+    if (!(depth < max_depth && hit.slot >= 0)) {
+        *radiance = background(bg, r);
+        return true;
+    }
+    uint32_t mat_id;
+    HitProps hp = slot_props(sc, hit.slot, r, hit.t, &mat_id);
+    hp.u = clampf(hp.u, 0.0f, 1.0f);  // aggregate.rs:31
+    hp.v = clampf(hp.v, 0.0f, 1.0f);
+    const rrt_material m = sc.materials[mat_id];
+    if (m.type == RRT_MAT_DIFFUSE_LIGHT) {  // material.rs:229-231: emission ends the path
+        *radiance = texture_value(sc, m.albedo, hp.u, hp.v, hp.p);
+        return true;
+    }
+    if (m.type == RRT_MAT_DIELECTRIC) {  // material.rs:172-207
+        float eta;
+        f3 n_use;
+        if (dot3(r.d, hp.n) < 0.0f) {
+            eta = 1.0f / m.param;
+            n_use = hp.n;
+        } else {
+            eta = m.param;
+            n_use = -hp.n;
+        }
+        f3 unit_dir = norm3(r.d);
+        float cos_theta = fmin_ref(dot3(-unit_dir, n_use), 1.0f);
+        float sin_theta = __builtin_sqrtf(1.0f - cos_theta * cos_theta);
+        f3 out;
+        if (eta * sin_theta > 1.0f) {
+            out = reflect_ref(unit_dir, n_use);
+        } else {
+            float reflect_prob = schlick_ref(cos_theta, eta);
+            if (rng_f32(g) < reflect_prob) out = reflect_ref(unit_dir, n_use);
+            else out = refract_ref(unit_dir, n_use, eta);
+        }
+        thr = thr * mk3(1.0f, 1.0f, 1.0f);
+        r.o = hp.p;
+        r.d = out;
+        return false;
+    }
+    if (m.type == RRT_MAT_ISOTROPIC) {  // volume.rs:27-35
+        f3 out = unit_sphere_random(g);
+        f3 att = texture_value(sc, m.albedo, hp.u, hp.v, hp.p);
+        thr = thr * att;
+        r.o = hp.p;
+        r.d = out;
+        return false;
+    }
+    f3 n = m.bump < 0 ? hp.n : bump_normal(sc, hp, m.bump);
+    if (m.type == RRT_MAT_METAL) {  // material.rs:145-160
+        f3 reflected = reflect_ref(norm3(r.d), n);
+        f3 out = reflected + m.param * unit_sphere_random(g);
+        f3 att = texture_value(sc, m.albedo, hp.u, hp.v, hp.p);
+        thr = thr * att;
+        r.o = hp.p;
+        r.d = out;
+        return false;
+    }
+    // Lambert (material.rs:98-110) + the PDF branch of trace (aggregate.rs:57-90)
+    f3 att = texture_value(sc, m.albedo, hp.u, hp.v, hp.p);
+    Ray scattered;
+    scattered.o = hp.p;
+    float pdf_val;
+    if (sc.n_lights > 0) {
+        float xi = rng_f32(g);  // pair_generate, pdf.rs:121-128
+        if (xi < 0.5f) {
+            uint32_t k = rng_index(g, sc.n_lights);
+            scattered.d = light_sample(sc, sc.lights[k], hp.p, g);
+        } else {
+            scattered.d = onb_local(n, random_cosine_direction(g));
+        }
+        pdf_val = mixture_value(sc, scattered) * 0.5f + cosine_value(n, scattered) * 0.5f;  // pair_value, pdf.rs:117-119
+    } else {
+        scattered.d = onb_local(n, random_cosine_direction(g));
+        pdf_val = cosine_value(n, scattered);
+    }
+    thr = (thr * (att * cosine_value(n, scattered))) / pdf_val;
+    r = scattered;
+    return false;
+}
+
+}  // namespace rrt
