@@ -572,23 +572,23 @@ static inline bool aabb_intersect(const AABB& b, const Ray& r, float t_min, floa
     if (c <= a) return false;
     return true;
 }
-// A conventional (complete) slab test, used only to count how many nodes an
-// implementation with a complete test needs to visit.  It never rejects a box
-// that the ray segment (t_min, t_max) truly overlaps: exits are widened by a few ulp.
+// The reference's test AND a complete slab-overlap test (smallest exit >= largest entry, widened by a 1e-5
+// relative margin).  It accepts a subset of what the reference accepts; it exists to count how many nodes an
+// implementation that culls this way visits, and to show that the closest hit does not change.
 static inline bool aabb_intersect_tight(const AABB& b, const Ray& r, float t_min, float t_max) {
-    float lo = t_min, hi = t_max;
+    if (!aabb_intersect(b, r, t_min, t_max)) return false;
+    float lo = t_min, ex = t_max;
     for (int axis = 0; axis < 3; ++axis) {
         float inv = 1.0f / axis_of(r.dir, axis);
         float t0 = (axis_of(b.min, axis) - axis_of(r.origin, axis)) * inv;
         float t1 = (axis_of(b.max, axis) - axis_of(r.origin, axis)) * inv;
         if (inv < 0.0f) std::swap(t0, t1);
         lo = t0 > lo ? t0 : lo;
-        hi = t1 < hi ? t1 : hi;
+        ex = t1 < ex ? t1 : ex;
     }
-    if (lo >= t_max) return false;          // same as the reference: entry at/after the closest hit
-    float hi_pad = hi + std::fabs(hi) * 1.0e-5f;
+    float ex_pad = ex + std::fabs(ex) * 1.0e-5f;
     float lo_pad = lo - std::fabs(lo) * 1.0e-5f;
-    return !(hi_pad < lo_pad);
+    return ex_pad >= lo_pad;
 }
 
 // ---------------------------------------------------------------------------

@@ -448,41 +448,35 @@ RRT_DEV void slab(float lo, float hi, float o, float inv, float* t0, float* t1) 
     *t0 = neg ? b : a;
     *t1 = neg ? a : b;
 }
-// The reference's test, verbatim: an exit is honoured only against the ENTRY bound (`t1 < t_min`).
-RRT_DEV bool aabb_reference(f3 bmin, f3 bmax, f3 o, f3 inv, float t_min, float t_max) {
-    float t0, t1;
-    slab(bmin.x, bmax.x, o.x, inv.x, &t0, &t1);
-    float lo = t0 > t_min ? t0 : t_min;
-    float hi = t1 < t_min ? t1 : t_max;
+// AABB::intersect (aggregate.rs:471-503).  REFERENCE mode is the reference's test verbatim: an exit is honoured
+// only against the running ENTRY bound (`t1 < t_min`), so many boxes the ray misses are still accepted.
+// TIGHT mode accepts a box only if the reference's test accepts it AND the slab intervals really overlap
+// (smallest exit >= largest entry, with a 1e-5 relative margin so that rounding never culls a box whose
+// primitive can be hit).  TIGHT therefore visits a subset of the reference's boxes and, for primitives that
+// lie inside their boxes, reports the same closest hit.
+template <int AABB_MODE>
+RRT_DEV bool aabb_test(f3 bmin, f3 bmax, f3 o, f3 inv, float t_min, float t_max) {
+    float t0x, t1x, t0y, t1y, t0z, t1z;
+    slab(bmin.x, bmax.x, o.x, inv.x, &t0x, &t1x);
+    slab(bmin.y, bmax.y, o.y, inv.y, &t0y, &t1y);
+    slab(bmin.z, bmax.z, o.z, inv.z, &t0z, &t1z);
+    float lo = t0x > t_min ? t0x : t_min;
+    float hi = t1x < t_min ? t1x : t_max;
     if (hi <= lo) return false;
-    slab(bmin.y, bmax.y, o.y, inv.y, &t0, &t1);
-    float lo2 = t0 > lo ? t0 : lo;
-    float hi2 = t1 < lo ? t1 : hi;
+    float lo2 = t0y > lo ? t0y : lo;
+    float hi2 = t1y < lo ? t1y : hi;
     if (hi2 <= lo2) return false;
-    slab(bmin.z, bmax.z, o.z, inv.z, &t0, &t1);
-    float lo3 = t0 > lo2 ? t0 : lo2;
-    float hi3 = t1 < lo2 ? t1 : hi2;
+    float lo3 = t0z > lo2 ? t0z : lo2;
+    float hi3 = t1z < lo2 ? t1z : hi2;
     if (hi3 <= lo3) return false;
-    return true;
-}
-// Complete slab test.  Accepts every box the reference's test accepts AND the segment can actually reach:
-// it rejects a box only when its entry is at/after t_max (as the reference does) or when its exit precedes its
-// entry by more than a 1e-5 relative margin, so rounding can never cull a box whose primitive the reference hits.
-RRT_DEV bool aabb_tight(f3 bmin, f3 bmax, f3 o, f3 inv, float t_min, float t_max) {
-    float lo = t_min, hi = t_max, t0, t1;
-    slab(bmin.x, bmax.x, o.x, inv.x, &t0, &t1);
-    lo = t0 > lo ? t0 : lo;
-    hi = t1 < hi ? t1 : hi;
-    slab(bmin.y, bmax.y, o.y, inv.y, &t0, &t1);
-    lo = t0 > lo ? t0 : lo;
-    hi = t1 < hi ? t1 : hi;
-    slab(bmin.z, bmax.z, o.z, inv.z, &t0, &t1);
-    lo = t0 > lo ? t0 : lo;
-    hi = t1 < hi ? t1 : hi;
-    if (lo >= t_max) return false;
-    float hi_pad = hi + __builtin_fabsf(hi) * 1.0e-5f;
-    float lo_pad = lo - __builtin_fabsf(lo) * 1.0e-5f;
-    return hi_pad >= lo_pad;
+    if (AABB_MODE == RRT_AABB_REFERENCE) return true;
+    float ex = t_max;
+    ex = t1x < ex ? t1x : ex;
+    ex = t1y < ex ? t1y : ex;
+    ex = t1z < ex ? t1z : ex;
+    float ex_pad = ex + __builtin_fabsf(ex) * 1.0e-5f;
+    float lo_pad = lo3 - __builtin_fabsf(lo3) * 1.0e-5f;
+    return ex_pad >= lo_pad;
 }
 
 // ---- closest hit: BVH::hit (aggregate.rs:324-401) with List::hit (aggregate.rs:144-165) in the leaves ------------
@@ -505,8 +499,7 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
         const float4 n1 = sc.nodes[2 * cur + 1];
         bool inside;
         if (sc.is_list) inside = true;
-        else if (AABB_MODE == RRT_AABB_REFERENCE) inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
-        else inside = aabb_tight(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
+        else inside = aabb_test<AABB_MODE>(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
         if (inside) {
             const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
             if (b & RRT_LEAF_FLAG) {

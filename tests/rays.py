@@ -30,7 +30,7 @@ def ray_batch(oracle_scene, W, H, n_random=4096, seed=0):
     # 3. secondary rays: start on surfaces found by batch 1
     p, t = oracle_scene.intersect(origins[0], dirs[0])
     hit = p >= 0
-    so = (origins[0] + dirs[0] * t[:, None])[hit].astype(np.float32)
+    so = (origins[0][hit] + dirs[0][hit] * t[hit, None]).astype(np.float32)
     sd = rng.normal(size=so.shape).astype(np.float32)
     origins.append(so)
     dirs.append(sd)
