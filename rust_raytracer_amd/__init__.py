@@ -99,6 +99,10 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise ImportError("librrt_hip.so has not been built (run `python rust_raytracer_amd/build.py`); there is no CPU fallback")
+    # PyTorch ships its own HIP runtime (libamdhip64.so.7).  Import it first so that this process holds exactly one
+    # runtime and torch tensors, streams and RCCL buffers are valid arguments to the *_device entry points.
+    import torch  # noqa: F401
+
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.rrt_last_error.restype = C.c_char_p
