@@ -63,6 +63,7 @@ def main():
     import torch.distributed as dist
 
     import rust_raytracer_amd as rrt
+    from rust_raytracer_amd import shard
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -82,7 +83,8 @@ def main():
     counters = torch.zeros(2, dtype=torch.int64, device=dev)
     aabb = rrt.AABB_TIGHT if args.aabb == "tight" else rrt.AABB_REFERENCE
     if args.shard == "samples":
-        kw = dict(samples=args.spp, first_sample=rank * args.spp, seed=0, aabb_mode=aabb)
+        first, count = shard.sample_range(rank, args.spp)
+        kw = dict(samples=count, first_sample=first, seed=0, aabb_mode=aabb)
     else:
         kw = dict(samples=args.spp, first_sample=0, seed=0, aabb_mode=aabb, tile_count=world, tile_index=rank)
 
@@ -95,8 +97,7 @@ def main():
         scene.render_device(img.data_ptr(), counters.data_ptr(), stream.cuda_stream, **kw)
         if ev1 is not None:
             ev1.record(stream)
-        if world > 1:
-            dist.reduce(img, dst=0, op=dist.ReduceOp.SUM)  # the one collective of the job
+        shard.reduce_frame(img, dst=0)  # the one collective of the job (no-op on one GPU)
 
     def fence():
         if world > 1:

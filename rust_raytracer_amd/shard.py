@@ -1,0 +1,31 @@
+"""Multi-GPU sharding of one frame: one process per GPU, scene replicated, one collective at the end.
+
+Two partitionings (both leave every (pixel, sample) with the same random stream as a single-GPU render):
+* sample ranges — rank r renders samples [r*spp, (r+1)*spp) of every pixel; partial sums are added with one reduce.
+* interleaved 32x32 tiles — rank r renders tiles whose index % world == r into a zeroed frame; since every pixel is
+  written by exactly one rank, the same sum-reduce reassembles the frame bit for bit (x + 0 == x).
+"""
+import numpy as np
+
+TILE = 32
+
+
+def sample_range(rank, spp_per_rank):
+    """(first_sample, samples) of `rank`."""
+    return rank * spp_per_rank, spp_per_rank
+
+
+def tile_owner_mask(width, height, world, rank):
+    """Boolean [H, W] mask of the pixels rank `rank` renders under interleaved 32x32 tiles."""
+    tiles_x = (width + TILE - 1) // TILE
+    ty, tx = np.meshgrid(np.arange(height) // TILE, np.arange(width) // TILE, indexing="ij")
+    return ((ty * tiles_x + tx) % world) == rank
+
+
+def reduce_frame(frame, dst=0):
+    """Sums the per-rank radiance frames onto rank `dst` (RCCL on GPU tensors, gloo on CPU tensors). In place."""
+    import torch.distributed as dist
+
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
+    return frame

@@ -1,0 +1,226 @@
+"""The product's host side (C++ scene loader, SAH BVH, flattening; no GPU needed) against the oracle and the format rules."""
+import ctypes as C
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+
+import orc
+import sceneio
+import rust_raytracer_amd as rrt
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SCENES = ["Cornell_Box.json", "Cornell_Box_With_Sphere.json", "Materials.json", "Example_Spec.json", "Globe.json"]
+
+
+def test_abi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "rrt.h")).read()
+    names = set(re.findall(r"\b(rrt_[a-z0-9_]+)\s*\(", header))
+    names -= {"rrt_status"}
+    assert len(names) >= 20
+    L = rrt.lib()
+    for n in sorted(names):
+        assert hasattr(L, n), "librrt_hip.so does not export %s" % n
+    assert rrt.version().startswith("rrt-mi355x")
+
+
+def test_struct_layouts_match_header_sizes():
+    assert C.sizeof(rrt._Node) == 32 and C.sizeof(rrt._Slot) == 48 and C.sizeof(rrt._TriShade) == 48
+    assert C.sizeof(rrt._Sphere) == 128 and C.sizeof(rrt._Medium) == 16 and C.sizeof(rrt._Material) == 16
+    assert C.sizeof(rrt._Texture) == 32 and C.sizeof(rrt._Light) == 96 and C.sizeof(rrt._Camera) == 76
+
+
+@pytest.mark.parametrize("name", SCENES)
+def test_flattened_bvh_equals_oracle_bvh(name):
+    hs = rrt.HostScene.load(orc.asset(name))
+    o = orc.OracleScene.from_file(orc.asset(name))
+    nodes, slots = hs.nodes(), hs.slots()
+    boxes, meta, leaf = o.bvh()
+    assert len(nodes) == len(meta)
+    assert np.array_equal(nodes["bmin"], boxes[:, :3]) and np.array_equal(nodes["bmax"], boxes[:, 3:])
+    is_leaf = (nodes["b"] & 0x80000000) != 0
+    assert np.array_equal(is_leaf.astype(np.int32), meta[:, 0])
+    inner = ~is_leaf
+    assert np.array_equal(nodes["b"][inner], meta[inner, 1].astype(np.uint32))  # cut axis
+    assert np.array_equal(nodes["a"][inner] - np.nonzero(inner)[0], meta[inner, 2].astype(np.uint32))  # right_offset
+    assert np.array_equal((nodes["b"][is_leaf] & 0x7FFFFFFF), meta[is_leaf, 3].astype(np.uint32))
+    assert np.array_equal(slots["prim"].astype(np.int32), leaf)  # leaf order of shapes
+    assert np.array_equal(hs.camera().view(np.uint32), o.camera().view(np.uint32))
+    # light list = important shapes in scene order
+    imp = o.important()
+    assert hs.desc.n_lights == len(imp)
+    d = hs.desc
+    assert d.bvh_depth >= 1 and d.n_slots == o.num_shapes()
+
+
+def test_triangle_slots_hold_v0_e1_e2():
+    hs = rrt.HostScene.load(orc.asset("Cornell_Box.json"))
+    desc = sceneio.read_scene(orc.asset("Cornell_Box.json"))
+    slots = hs.slots()
+    # first shape of the file: Square.obj scaled to 555 x 555, rotated -90 deg about y, at x = 555 (the green wall)
+    s = slots[np.nonzero(slots["prim"] == 0)[0][0]]
+    v0, e1, e2 = s["v0"], s["e1"], s["e2"]
+    assert abs(v0[0] - 555) < 1e-3 and abs(e1[0]) < 1e-3 and abs(e2[0]) < 1e-3
+    assert (s["info"] >> 30) == rrt.KIND_TRIANGLE and (s["info"] & (1 << 28))  # culling on
+    assert len(desc["shapes"]) == 8  # 6 squares + 2 cubes as meshes -> 36 triangles
+    assert hs.desc.n_slots == 36
+    lights = hs.lights()
+    assert len(lights) == 2 and np.all(lights["kind"] == rrt.KIND_TRIANGLE)
+    assert lights["area"][0] == pytest.approx(0.5 * 130 * 105, rel=1e-5)
+
+
+def test_jpeg_decoder_matches_pil_for_the_shipped_textures():
+    hs = rrt.HostScene.load(orc.asset("Globe.json"))
+    tex, px = hs.textures(), hs.texels()
+    for t, fn in zip(tex, ["earthmap1k.jpg", "earthbump1k.jpg"]):  # "World", "WorldBump" in key order
+        ref = sceneio.load_image(orc.asset(fn))
+        got = px[t["u3"]: t["u3"] + int(t["u0"]) * int(t["u1"]) * int(t["u2"])].reshape(t["u1"], t["u0"], t["u2"])
+        assert got.shape == ref.shape and np.array_equal(got, ref)
+
+
+def test_png_and_pnm_textures(tmp_path):
+    from PIL import Image
+
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, (13, 17, 3), dtype=np.uint8)
+    grey = rng.integers(0, 256, (9, 5), dtype=np.uint8)
+    Image.fromarray(rgb).save(tmp_path / "a.png")
+    Image.fromarray(grey).save(tmp_path / "g.png")
+    Image.fromarray(rgb).save(tmp_path / "a.ppm")
+    Image.fromarray(rgb).convert("RGBA").save(tmp_path / "rgba.png")
+    scene = {"Logistics": {"resolution_x": 8, "resolution_y": 8, "samples": 1},
+             "Camera": {"position": [0, 0, 1], "look_at": [0, 0, 0], "up": [0, 1, 0], "fov": 90, "aspect_ratio": 1, "aperture": 0, "focus_distance": 1},
+             "Textures": {"A": {"type": "Image", "image_path": "a.png"}, "B": {"type": "Image", "image_path": "g.png"},
+                          "C": {"type": "Image", "image_path": "a.ppm"}, "D": {"type": "Image", "image_path": "rgba.png"},
+                          "E": {"type": "Image", "image_path": "a.png"}},
+             "Materials": {"M": {"type": "Lambert", "albedo": "A"}}, "Aggregate": "BVH",
+             "Shapes": [{"type": "Sphere", "radius": 0.5, "material": "M"}]}
+    (tmp_path / "s.json").write_text(json.dumps(scene))
+    hs = rrt.HostScene.load(str(tmp_path / "s.json"))
+    tex, px = hs.textures(), hs.texels()
+
+    def texels(i):
+        t = tex[i]
+        return px[t["u3"]: t["u3"] + int(t["u0"]) * int(t["u1"]) * int(t["u2"])].reshape(t["u1"], t["u0"], t["u2"])
+
+    assert np.array_equal(texels(0), rgb) and np.array_equal(texels(1)[:, :, 0], grey)
+    assert np.array_equal(texels(2), rgb) and np.array_equal(texels(3), rgb)
+    assert tex[4]["u3"] == tex[0]["u3"]  # the same file is decoded once (resources.rs:34-39)
+
+
+BASE = {"Logistics": {"resolution_x": 8, "resolution_y": 8, "samples": 1},
+        "Camera": {"position": [0, 0, 1], "look_at": [0, 0, 0], "up": [0, 1, 0], "fov": 90, "aspect_ratio": 1, "aperture": 0, "focus_distance": 1},
+        "Textures": {"T": {"type": "Constant", "color": [1, 1, 1]}}, "Materials": {"M": {"type": "Lambert", "albedo": "T"}},
+        "Aggregate": "BVH", "Shapes": [{"type": "Sphere", "radius": 1, "material": "M"}]}
+
+
+def load_variant(tmp_path, mutate):
+    s = json.loads(json.dumps(BASE))
+    mutate(s)
+    p = tmp_path / "v.json"
+    p.write_text(json.dumps(s))
+    return rrt.HostScene.load(str(p))
+
+
+@pytest.mark.parametrize("mutate,message", [
+    (lambda s: s.pop("Camera"), "Required key Camera is missing."),
+    (lambda s: s.pop("Aggregate"), "Required key Aggregate is missing."),
+    (lambda s: s.__setitem__("Aggregate", "Grid"), "Unknown Aggregate 'type' Grid given."),
+    (lambda s: s["Shapes"][0].__setitem__("material", "Nope"), "Missing Material Nope for Sphere."),
+    (lambda s: s["Materials"]["M"].__setitem__("albedo", "Nope"), "Missing Texture Nope for Lambert."),
+    (lambda s: s["Materials"]["M"].__setitem__("bump_map", "Nope"), "Missing bump map Texture Nope for Lambert."),
+    (lambda s: s["Materials"]["M"].__setitem__("type", "Phong"), "Unsupported material type: Phong"),
+    (lambda s: s["Textures"]["T"].__setitem__("type", "Marble"), "Unsupported texture type: Marble"),
+    (lambda s: s["Shapes"][0].__setitem__("type", "Cylinder"), "Unknown Shape 'type' Cylinder given."),
+    (lambda s: s["Textures"].__setitem__("U", {"type": "Turbulence", "scale": 1, "depth": 2, "omega": 1.5}), "Turbulence omega is greater than 1."),
+    (lambda s: s["Camera"].__setitem__("position", [0, 0]), "Deserializing in to Point3 requires a Vec of length 3!"),
+    (lambda s: s["Shapes"][0].__setitem__("transform", {"scale": [0, 1, 1]}), "Singular matrix"),
+    (lambda s: s.__setitem__("Shapes", {}), "'Shapes' is not a JSON array."),
+])
+def test_loader_errors_mirror_the_reference(tmp_path, mutate, message):
+    with pytest.raises(rrt.RrtError) as e:
+        load_variant(tmp_path, mutate)
+    assert e.value.code == 2 and message in e.value.message
+    # the test-side reader refuses the same files
+    s = json.loads(json.dumps(BASE))
+    mutate(s)
+    (tmp_path / "w.json").write_text(json.dumps(s))
+    with pytest.raises(Exception):
+        orc.OracleScene.from_file(str(tmp_path / "w.json"))
+
+
+def test_mesh_rules(tmp_path):
+    # multi-object .obj with per-object indices, vt indices, a quad (fan-triangulated) and a degenerate triangle error
+    (tmp_path / "m.obj").write_text("o A\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 2/2 3/3 4/4\n"
+                                    "o B\nv 0 0 1\nv 1 0 1\nv 0 1 1\nf 5 6 7\n")
+
+    def m(s):
+        s["Shapes"] = [{"type": "Mesh", "file_path": "m.obj", "enable_backface_culling": False, "material": "M"}]
+
+    hs = load_variant(tmp_path, m)
+    slots = hs.slots()
+    assert hs.desc.n_slots == 3
+    o = orc.OracleScene.from_file(str(tmp_path / "v.json"))
+    assert np.array_equal(slots["prim"].astype(np.int32), o.bvh()[2])
+    (tmp_path / "m.obj").write_text("o A\nv 0 0 0\nv 1 0 0\nv 2 0 0\nf 1 2 3\n")
+    with pytest.raises(rrt.RrtError) as e:
+        load_variant(tmp_path, m)
+    assert "Error creating Triangle for file m.obj, object A: Triangle texture coordinates are degenerate." in e.value.message
+    (tmp_path / "m.obj").write_text("o A\nv 0 0 0\nv 1 0 0\nv 2 1 0\nf 1 2 9\n")
+    with pytest.raises(rrt.RrtError) as e:
+        load_variant(tmp_path, m)
+    assert "Triangle mesh has length 3 but attempted to make a Triangle with indices 0, 1, 8." in e.value.message
+
+
+def test_builder_api_and_list_aggregate():
+    hs = rrt.HostScene.new()
+    t = hs.add_texture(rrt.lib() and 0, 0.5, 0.5, 0.5)
+    light_t = hs.add_texture(0, 4.0, 4.0, 4.0)
+    m = hs.add_material(0, t)
+    lm = hs.add_material(3, light_t)
+    hs.add_sphere(1.0, m, translate=(0, 0, -3))
+    hs.add_mesh([[-1, 2, -4], [1, 2, -4], [1, 2, -2], [-1, 2, -2]], [[0, 1, 2], [0, 2, 3]], lm)
+    hs.set_camera((0, 0, 1), (0, 0, 0), (0, 1, 0), 60, 1.0, 0.0, 1.0)
+    hs.set_logistics(16, 16, 2)
+    hs.finalize("List")
+    d = hs.desc
+    assert d.aggregate_is_list == 1 and d.n_nodes == 1 and d.n_slots == 3 and d.n_lights == 2
+    assert list(hs.slots()["prim"]) == [0, 1, 2]  # scene order
+    with pytest.raises(rrt.RrtError):
+        hs.add_material(0, 99)
+
+
+def test_synthetic_mesh_bvh_matches_oracle_at_scale():
+    """A 20k-triangle soup: the product's in-place range builder and the oracle's recursive builder give the same tree."""
+    rng = np.random.default_rng(1)
+    n = 20000
+    c = rng.uniform(-1, 1, (n, 1, 3))
+    v = (c + rng.normal(scale=0.01, size=(n, 3, 3))).reshape(-1, 3)
+    idx = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    hs = rrt.HostScene.new()
+    t = hs.add_texture(0, 0.5, 0.5, 0.5)
+    m = hs.add_material(0, t)
+    hs.add_mesh(v, idx, m)
+    hs.set_camera((0, 0, 3), (0, 0, 0), (0, 1, 0), 60, 1.0, 0.0, 1.0)
+    hs.set_logistics(16, 16, 1)
+    hs.finalize("BVH")
+    L = orc.lib()
+    h = L.orc_scene_new()
+    L.orc_add_texture_constant(h, 0.5, 0.5, 0.5)
+    L.orc_add_material(h, 0, 0, -1, 0.0)
+    z, one = orc.a32([0, 0, 0]), orc.a32([1, 1, 1])
+    assert L.orc_add_mesh(h, z, z, one, len(v), np.ascontiguousarray(v).reshape(-1), 0, np.zeros(2), n, idx.reshape(-1), np.full(3 * n, -1, np.int32), 0, 0, 0) == n
+    L.orc_set_logistics(h, 16, 16, 1, 1)
+    L.orc_finalize(h, 1)
+    nn = L.orc_bvh_num_nodes(h)
+    meta = np.zeros((nn, 4), dtype=np.int32)
+    boxes = np.zeros((nn, 6), dtype=np.float32)
+    leaf = np.zeros(n, dtype=np.int32)
+    L.orc_bvh_export(h, boxes.ctypes.data, meta.ctypes.data, leaf.ctypes.data)
+    L.orc_scene_free(h)
+    nodes = hs.nodes()
+    assert len(nodes) == nn and np.array_equal(hs.slots()["prim"].astype(np.int32), leaf)
+    assert np.array_equal(nodes["bmin"], boxes[:, :3]) and np.array_equal(nodes["bmax"], boxes[:, 3:])
+    assert nn > 1000
