@@ -65,9 +65,12 @@ typedef struct rrt_slot {
 #define RRT_INFO_KIND(info) ((info) >> 30)
 #define RRT_INFO_MATERIAL(info) ((info)&0x00ffffffu)
 
-/* Per-triangle shading record, 48 bytes, same index as the slot: texture coordinates
+/* Per-triangle shading record, 64 bytes, same index as the slot: the unit normal normalized(e1 x e2) as
+ * Triangle::get_hit_properties forms it (shape.rs:390, before the back-face flip), texture coordinates
  * (shape.rs:190-210 defaults applied) and the cached dp/du, dp/dv of Triangle::new (shape.rs:278-314). */
 typedef struct rrt_tri_shade {
+    float nrm[3];
+    uint32_t pad;
     float uv0[2], uv1[2], uv2[2];
     float pu[3];
     float pv[3];

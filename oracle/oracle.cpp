@@ -1629,9 +1629,10 @@ void orc_camera_rays(void* s, uint32_t W, uint32_t H, uint32_t seed, uint64_t n,
 // rgb_sum is row-major [y][x][3] (the reference's internal buffer is column-major x*res_y+y, main.rs:244).
 // flags: bit0 = recursive trace (faithful form) instead of the loop form; bit1 = complete slab test.
 // Rows are split over `threads` std::threads; each pixel sums its samples in sample order, so the
-// result does not depend on the thread count.  stats4 = {rays, nodes, tri_tests, sphere_tests}.
+// result does not depend on the thread count.  stats4 = {rays, nodes, tri_tests, sphere_tests};
+// rays_per_pixel (optional, W*H) receives the number of rays each pixel's samples traced.
 void orc_render(void* s, uint32_t W, uint32_t H, uint32_t spp, uint32_t first_sample, uint32_t seed, int bg, int flags, int max_depth, int threads,
-                uint32_t y0, uint32_t y1, float* rgb_sum, uint64_t* stats4) {
+                uint32_t y0, uint32_t y1, float* rgb_sum, uint64_t* stats4, uint32_t* rays_per_pixel) {
     Scene* sc = (Scene*)s;
     if (threads < 1) threads = 1;
     if (max_depth < 0) max_depth = kMaxDepth;
@@ -1648,6 +1649,7 @@ void orc_render(void* s, uint32_t W, uint32_t H, uint32_t spp, uint32_t first_sa
             if (y >= y1) break;
             for (uint32_t x = 0; x < W; ++x) {
                 RGB sum = v3(0, 0, 0);
+                const uint64_t rays_before = st.rays;
                 for (uint32_t k = 0; k < spp; ++k) {
                     Rng g = rng_seed(seed, y * W + x, first_sample + k);
                     float u = ((float)x + rng_f32(g)) / (float)W;          // main.rs:227
@@ -1658,6 +1660,7 @@ void orc_render(void* s, uint32_t W, uint32_t H, uint32_t spp, uint32_t first_sa
                 }
                 float* q = rgb_sum + ((size_t)y * W + x) * 3;
                 q[0] = sum.x; q[1] = sum.y; q[2] = sum.z;
+                if (rays_per_pixel) rays_per_pixel[(size_t)y * W + x] = (uint32_t)(st.rays - rays_before);
             }
         }
     };

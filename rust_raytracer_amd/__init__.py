@@ -37,7 +37,8 @@ class _Slot(C.Structure):
 
 
 class _TriShade(C.Structure):
-    _fields_ = [("uv0", C.c_float * 2), ("uv1", C.c_float * 2), ("uv2", C.c_float * 2), ("pu", C.c_float * 3), ("pv", C.c_float * 3)]
+    _fields_ = [("nrm", C.c_float * 3), ("pad", C.c_uint32), ("uv0", C.c_float * 2), ("uv1", C.c_float * 2), ("uv2", C.c_float * 2),
+                ("pu", C.c_float * 3), ("pv", C.c_float * 3)]
 
 
 class _Sphere(C.Structure):

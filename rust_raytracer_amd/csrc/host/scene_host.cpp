@@ -293,6 +293,8 @@ void fill_tri_slot(const HostShape& s, uint32_t prim, rrt_slot* slot, rrt_tri_sh
     slot->prim = prim;
     slot->info = (RRT_KIND_TRIANGLE << 30) | (s.cull ? RRT_INFO_CULL : 0u) | (s.material & 0x00ffffffu);
     slot->aux = 0;
+    put3(sd->nrm, normalized(cross(s.v1 - s.v0, s.v2 - s.v0)));
+    sd->pad = 0;
     std::memcpy(sd->uv0, s.uv, sizeof(float) * 6);
     put3(sd->pu, s.pu);
     put3(sd->pv, s.pv);

@@ -12,72 +12,97 @@ using namespace rrt;
 
 namespace {
 
-constexpr int kBlock = 256;            // 4 waves: a 16x16-pixel quadrant of a 32x32 tile, one 8x8 tile per wave
-constexpr uint32_t kMaxStackDepth = 64;  // LDS short stack: entries per lane (16 KiB per block at 64)
+constexpr int kBlock = 256;              // k_intersect: 4 waves per block
+constexpr int kTraceBlock = 64;          // k_trace: one wave per block, the unit the hardware dispatcher balances
+constexpr uint32_t kChunk = 64;          // samples of each pixel handled by one wave item
+constexpr uint32_t kMaxStackDepth = 64;  // LDS short stack: entries per lane
+constexpr size_t kSlabCapBytes = 4ull << 30;  // per-sample radiance staging buffer (per scene handle, per GPU)
 
-struct RenderArgs {
-    uint32_t W, H, spp, first_sample, seed, bg, max_depth;
-    uint32_t tile_count, tile_index, tiles_x, n_tiles;  // 32x32 tiles
+struct TraceArgs {
+    uint32_t W, H;
+    uint32_t first_sample;  // stream index of the pass's first sample
+    uint32_t n_samples;     // samples per pixel in this pass
+    uint32_t seed, bg, max_depth;
+    uint32_t tile_count, tile_index, tiles_x, n_tiles;  // 32x32-pixel tiles (multi-GPU sharding unit)
+    uint32_t n_t8;                                       // 8x8-pixel wave tiles owned by this call
 };
 
-// ---- the render kernel -------------------------------------------------------------------------------
-// One lane owns one pixel and walks that pixel's samples in order; when a path ends the lane adds its
-// radiance to the pixel sum held in registers and immediately starts the next sample (path regeneration),
-// so lanes stay busy regardless of how long neighbouring paths are.  Path state (ray, throughput, RNG)
-// never leaves registers; the only HBM traffic is the scene (cache resident) and one 12-byte store per pixel.
-// ≙ main.rs:200-257 (thread_work) + aggregate.rs:16-105 (trace).
-template <int AABB_MODE>
-__global__ __launch_bounds__(kBlock) void k_render(DScene sc, RenderArgs ra, float* __restrict__ rgb_sum, unsigned long long* __restrict__ counters) {
+// ---- the trace kernel -------------------------------------------------------------------------------------
+// ≙ main.rs:200-257 (thread_work) + aggregate.rs:16-105 (trace), for one pass of `n_samples` samples per pixel.
+//
+// A wave owns an 8x8-pixel tile and a chunk of up to 64 consecutive samples of each of its pixels: a pool of
+// 64 x chunk camera samples.  Lanes draw samples from that pool one at a time (ballot + prefix count, no memory
+// traffic): when a lane's path ends it stores the path's radiance and immediately starts the next undrawn sample, so
+// lanes never wait for a neighbour's longer path, and the dispatcher balances the (tile, chunk) items across the chip.
+// Path state (ray, throughput, RNG) lives in registers for the whole path; the BVH short stack is in LDS.
+// Every sample's radiance goes to slab[sample][y][x] (12 bytes per path); k_accumulate then adds a pixel's samples in
+// sample order, which makes the image independent of how samples were scheduled.
+template <int AABB_MODE, uint32_t FEAT>
+__global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
     extern __shared__ uint32_t lds_stack[];
-    const uint32_t tid = threadIdx.x;
-    const uint32_t wave = tid >> 6, lane = tid & 63u;
-    const uint32_t tile = ra.tile_index + (blockIdx.x >> 2) * ra.tile_count;  // this block's 32x32 tile
-    const uint32_t quad = blockIdx.x & 3u;
-    const uint32_t tx = tile % ra.tiles_x, ty = tile / ra.tiles_x;
-    const uint32_t x = tx * 32u + (quad & 1u) * 16u + (wave & 1u) * 8u + (lane & 7u);
-    const uint32_t y = ty * 32u + (quad >> 1) * 16u + (wave >> 1) * 8u + (lane >> 3);
-    const bool valid = tile < ra.n_tiles && x < ra.W && y < ra.H;
-    uint32_t* stack = lds_stack + tid;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t chunk = blockIdx.x / ta.n_t8, j = blockIdx.x % ta.n_t8;
+    const uint32_t tile32 = ta.tile_index + (j >> 4) * ta.tile_count;
+    const uint32_t x0 = (tile32 % ta.tiles_x) * 32u + ((j & 3u) << 3);
+    const uint32_t y0 = (tile32 / ta.tiles_x) * 32u + (((j >> 2) & 3u) << 3);
+    const uint32_t s0 = chunk * kChunk;
+    const uint32_t ns = ta.n_samples - s0 < kChunk ? ta.n_samples - s0 : kChunk;
+    const uint32_t pool = ns * 64u;
+    uint32_t* stack = lds_stack + lane;
 
-    f3 sum = mk3(0.0f, 0.0f, 0.0f);
-    unsigned long long rays = 0;
-    uint32_t s = 0;
-    bool alive = valid && ra.spp > 0;
+    uint32_t next = 64u;  // next undrawn pool index (wave-uniform)
+    uint32_t idx = lane;
+    bool alive = idx < pool;
     bool fresh = true;
+    bool valid = false;
+    unsigned long long rays = 0, paths = 0;
+    uint32_t px = 0, py = 0, smp = 0, depth = 0;
     Ray r;
     f3 thr;
     Rng g;
-    uint32_t depth = 0;
     r.o = r.d = thr = mk3(0.0f, 0.0f, 0.0f);
     g.s0 = g.s1 = 0;
     while (alive) {
         if (fresh) {
-            g = rng_seed(ra.seed, y * ra.W + x, ra.first_sample + s);
-            r = camera_ray(sc.cam, x, y, ra.W, ra.H, g);
-            thr = mk3(1.0f, 1.0f, 1.0f);
-            depth = 0;
+            px = x0 + (idx & 7u);
+            py = y0 + ((idx >> 3) & 7u);
+            smp = s0 + (idx >> 6);
+            valid = px < ta.W && py < ta.H;
+            if (valid) {
+                g = rng_seed(ta.seed, py * ta.W + px, ta.first_sample + smp);
+                r = camera_ray(sc.cam, px, py, ta.W, ta.H, g);
+                thr = mk3(1.0f, 1.0f, 1.0f);
+                depth = 0;
+                ++paths;
+            }
             fresh = false;
         }
-        Hit hit = closest_hit<AABB_MODE>(sc, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kBlock);
-        ++rays;
-        f3 radiance;
-        if (shade(sc, hit, r, thr, g, depth, ra.max_depth, ra.bg, &radiance)) {
-            sum = sum + thr * radiance;  // main.rs:244-245
-            ++s;
-            fresh = true;
-            alive = s < ra.spp;
-        } else {
-            ++depth;
+        bool done = true;
+        if (valid) {
+            Hit hit = closest_hit<AABB_MODE, FEAT>(sc, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock);
+            ++rays;
+            f3 radiance;
+            done = shade<FEAT>(sc, hit, r, thr, g, depth, ta.max_depth, ta.bg, &radiance);
+            if (done) {
+                f3 c = thr * radiance;
+                float* q = slab + (((size_t)smp * ta.H + py) * ta.W + px) * 3;
+                q[0] = c.x;
+                q[1] = c.y;
+                q[2] = c.z;
+            } else {
+                ++depth;
+            }
         }
-    }
-    if (valid) {
-        float* q = rgb_sum + ((size_t)y * ra.W + x) * 3;
-        q[0] = sum.x;
-        q[1] = sum.y;
-        q[2] = sum.z;
+        const unsigned long long finished = __ballot(done);
+        if (done) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(finished >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)finished, 0u));
+            idx = next + rank;
+            alive = idx < pool;
+            fresh = true;
+        }
+        next += (uint32_t)__popcll(finished);
     }
     if (counters) {
-        unsigned long long paths = valid ? (unsigned long long)ra.spp : 0ull;
         for (int off = 32; off > 0; off >>= 1) {
             rays += __shfl_down(rays, off);
             paths += __shfl_down(paths, off);
@@ -87,6 +112,22 @@ __global__ __launch_bounds__(kBlock) void k_render(DScene sc, RenderArgs ra, flo
             atomicAdd(&counters[1], paths);
         }
     }
+}
+
+// Adds each pixel's samples of one pass in sample order (main.rs:244-245: colors[p] = colors[p] + pixel_color).
+// One thread per float of the frame; reads are coalesced across the frame for every sample.
+__global__ void k_accumulate(const float* __restrict__ slab, uint32_t n_samples, size_t frame_floats, uint32_t W, uint32_t tiles_x, uint32_t tile_count,
+                             uint32_t tile_index, int first_pass, float* __restrict__ rgb_sum) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= frame_floats) return;
+    if (tile_count > 1) {
+        size_t pixel = i / 3;
+        uint32_t x = (uint32_t)(pixel % W), y = (uint32_t)(pixel / W);
+        if (((y >> 5) * tiles_x + (x >> 5)) % tile_count != tile_index) return;  // another rank's pixel: leave untouched
+    }
+    float sum = first_pass ? 0.0f : rgb_sum[i];
+    for (uint32_t s = 0; s < n_samples; ++s) sum = sum + slab[(size_t)s * frame_floats + i];
+    rgb_sum[i] = sum;
 }
 
 // ≙ Aggregate::hit (aggregate.rs:118-124) for a batch of rays, one lane per ray.
@@ -100,7 +141,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, const float* __
     r.o = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
     r.d = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     Rng g = rng_seed(seed, (uint32_t)i, 0);
-    Hit h = closest_hit<AABB_MODE>(sc, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock);
+    Hit h = closest_hit<AABB_MODE, F_ALL>(sc, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock);
     prim[i] = h.slot >= 0 ? (int)__float_as_uint(sc.slots[3 * h.slot].w) : -1;
     t_hit[i] = h.t;
 }
@@ -145,7 +186,13 @@ __global__ void k_probe(DScene sc, uint32_t which, uint32_t arg, uint32_t W, uin
             return;
         }
         uint32_t mat;
-        HitProps h = slot_props(sc, slot, r, t, &mat);
+        Hit hit;
+        hit.slot = slot;
+        hit.t = t;
+        hit.u = hit.v = hit.det = 0.0f;
+        if (RRT_INFO_KIND(__float_as_uint(sc.slots[3 * slot + 1].w)) == RRT_KIND_TRIANGLE)
+            triangle_uvdet(xyz(sc.slots[3 * slot]), xyz(sc.slots[3 * slot + 1]), xyz(sc.slots[3 * slot + 2]), r, &hit.u, &hit.v, &hit.det);
+        HitProps h = slot_props<F_ALL>(sc, hit, r, &mat);
         q[0] = h.p.x; q[1] = h.p.y; q[2] = h.p.z; q[3] = h.n.x; q[4] = h.n.y; q[5] = h.n.z; q[6] = h.u; q[7] = h.v;
         q[8] = h.pu.x; q[9] = h.pu.y; q[10] = h.pu.z; q[11] = h.pv.x; q[12] = h.pv.y; q[13] = h.pv.z;
     } else if (which == 2) {
@@ -186,7 +233,10 @@ int upload(const T* src, size_t count, const void** dst, std::vector<void*>* own
 struct rrt_scene {
     DScene d{};
     std::vector<void*> owned;
+    float* slab = nullptr;  // per-sample radiance staging, allocated on first render
+    size_t slab_bytes = 0;
     uint32_t res_x = 0, res_y = 0, samples = 0, stack_depth = 1;
+    uint32_t features = 0;  // F_* bits the scene needs
     uint32_t n_spheres = 0, n_media = 0, n_btris = 0, n_materials = 0, n_textures = 0;
     int device = 0;
 };
@@ -287,11 +337,11 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     } while (0)
     UP(nodes, (const float4*)desc->nodes, (size_t)desc->n_nodes * 2);
     UP(slots, (const float4*)desc->slots, (size_t)desc->n_slots * 3);
-    UP(tri_shade, (const float4*)desc->tri_shade, (size_t)desc->n_slots * 3);
+    UP(tri_shade, (const float4*)desc->tri_shade, (size_t)desc->n_slots * 4);
     UP(spheres, desc->spheres, desc->n_spheres);
     UP(media, desc->media, desc->n_media);
     UP(btris, (const float4*)desc->boundary_tris, (size_t)desc->n_boundary_tris * 3);
-    UP(btri_shade, (const float4*)desc->boundary_tri_shade, (size_t)desc->n_boundary_tris * 3);
+    UP(btri_shade, (const float4*)desc->boundary_tri_shade, (size_t)desc->n_boundary_tris * 4);
     UP(materials, desc->materials, desc->n_materials);
     UP(textures, desc->textures, desc->n_textures);
     UP(texels, desc->texels, desc->texel_bytes);
@@ -307,6 +357,20 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     s->samples = desc->samples;
     s->stack_depth = desc->bvh_depth ? desc->bvh_depth : 1;
     s->n_textures = desc->n_textures;
+    // which code the scene needs (see F_* in rrt_device.hpp)
+    for (uint32_t i = 0; i < desc->n_slots; ++i) {
+        uint32_t kind = RRT_INFO_KIND(desc->slots[i].info);
+        if (kind == RRT_KIND_SPHERE) s->features |= F_SPHERE;
+        if (kind == RRT_KIND_MEDIUM) s->features |= F_MEDIUM | F_SPHERE;
+    }
+    for (uint32_t i = 0; i < desc->n_lights; ++i)
+        if (desc->lights[i].kind == RRT_KIND_SPHERE) s->features |= F_SPHERE;
+    for (uint32_t i = 0; i < desc->n_textures; ++i)
+        if (desc->textures[i].type != RRT_TEX_CONSTANT) s->features |= F_TEX;
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+        if (desc->materials[i].bump >= 0) s->features |= F_BUMP | F_TEX;
+        if (desc->materials[i].type == RRT_MAT_ISOTROPIC) s->features |= F_MEDIUM;
+    }
     *out = s;
     return RRT_OK;
 }
@@ -314,6 +378,7 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
 void rrt_scene_destroy(rrt_scene* s) {
     if (!s) return;
     for (void* p : s->owned) (void)hipFree(p);
+    if (s->slab) (void)hipFree(s->slab);
     delete s;
 }
 
@@ -362,54 +427,98 @@ int rrt_intersect_batch(rrt_scene* s, const float* o, const float* d, size_t n, 
     return RRT_OK;
 }
 
-static int fill_render_args(rrt_scene* s, const rrt_render_params* p, RenderArgs* ra, unsigned* grid) {
+struct RenderPlan {
+    TraceArgs ta;
+    uint32_t spp;
+};
+
+static int plan_render(rrt_scene* s, const rrt_render_params* p, RenderPlan* plan) {
     if (!s || !p) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: NULL argument");
     if (p->aabb_mode > RRT_AABB_REFERENCE) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: unknown aabb_mode");
     if (p->background > RRT_BG_SKY) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: unknown background");
-    ra->W = p->width ? p->width : s->res_x;
-    ra->H = p->height ? p->height : s->res_y;
-    ra->spp = p->samples ? p->samples : s->samples;
-    if (ra->W == 0 || ra->H == 0) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: zero resolution");
-    if ((uint64_t)ra->W * ra->H > 0xffffffffull) return rrt_set_error(RRT_ERR_LIMIT, "rrt_render: more than 2^32 pixels");
-    ra->first_sample = p->first_sample;
-    ra->seed = p->seed;
-    ra->bg = p->background;
-    ra->max_depth = p->max_depth < 0 ? 50u : (uint32_t)p->max_depth;
-    ra->tile_count = p->tile_count ? p->tile_count : 1;
-    ra->tile_index = p->tile_index;
-    if (ra->tile_index >= ra->tile_count) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: tile_index >= tile_count");
-    ra->tiles_x = (ra->W + 31) / 32;
-    uint32_t tiles_y = (ra->H + 31) / 32;
-    ra->n_tiles = ra->tiles_x * tiles_y;
-    uint32_t mine = ra->n_tiles > ra->tile_index ? (ra->n_tiles - ra->tile_index + ra->tile_count - 1) / ra->tile_count : 0;
-    *grid = mine * 4;
+    TraceArgs& ta = plan->ta;
+    ta.W = p->width ? p->width : s->res_x;
+    ta.H = p->height ? p->height : s->res_y;
+    plan->spp = p->samples ? p->samples : s->samples;
+    if (ta.W == 0 || ta.H == 0) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: zero resolution");
+    if ((uint64_t)ta.W * ta.H > 0xffffffffull) return rrt_set_error(RRT_ERR_LIMIT, "rrt_render: more than 2^32 pixels");
+    ta.first_sample = p->first_sample;
+    ta.n_samples = 0;
+    ta.seed = p->seed;
+    ta.bg = p->background;
+    ta.max_depth = p->max_depth < 0 ? 50u : (uint32_t)p->max_depth;
+    ta.tile_count = p->tile_count ? p->tile_count : 1;
+    ta.tile_index = p->tile_index;
+    if (ta.tile_index >= ta.tile_count) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: tile_index >= tile_count");
+    ta.tiles_x = (ta.W + 31) / 32;
+    ta.n_tiles = ta.tiles_x * ((ta.H + 31) / 32);
+    uint32_t mine = ta.n_tiles > ta.tile_index ? (ta.n_tiles - ta.tile_index + ta.tile_count - 1) / ta.tile_count : 0;
+    ta.n_t8 = mine * 16u;
     return RRT_OK;
 }
 
 int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum, uint64_t* d_counters, void* stream) {
-    RenderArgs ra;
-    unsigned grid;
-    int rc = fill_render_args(s, p, &ra, &grid);
+    RenderPlan plan;
+    int rc = plan_render(s, p, &plan);
     if (rc) return rc;
     if (!d_rgb_sum) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: NULL output");
-    if (grid == 0) return RRT_OK;
-    size_t lds = (size_t)kBlock * s->stack_depth * sizeof(uint32_t);
+    TraceArgs ta = plan.ta;
+    if (ta.n_t8 == 0 || plan.spp == 0) return RRT_OK;
+    const size_t frame_floats = (size_t)ta.W * ta.H * 3;
+    const size_t frame_bytes = frame_floats * sizeof(float);
+    // samples per pass: as many as fit the staging buffer, in whole chunks when possible
+    uint64_t per_pass = kSlabCapBytes / frame_bytes;
+    if (per_pass == 0) per_pass = 1;
+    if (per_pass > plan.spp) per_pass = plan.spp;
+    if (per_pass >= kChunk) per_pass -= per_pass % kChunk;
+    const size_t need_bytes = (size_t)per_pass * frame_bytes;
+    if (s->slab_bytes < need_bytes) {
+        if (s->slab) {
+            HIP_TRY(hipDeviceSynchronize());  // earlier renders on any stream may still read the old buffer
+            HIP_TRY(hipFree(s->slab));
+            s->slab = nullptr;
+            s->slab_bytes = 0;
+        }
+        HIP_TRY(hipMalloc((void**)&s->slab, need_bytes));
+        s->slab_bytes = need_bytes;
+    }
+    const size_t lds = (size_t)kTraceBlock * s->stack_depth * sizeof(uint32_t);
     hipStream_t st = (hipStream_t)stream;
-    if (p->aabb_mode == RRT_AABB_REFERENCE)
-        hipLaunchKernelGGL(k_render<RRT_AABB_REFERENCE>, dim3(grid), dim3(kBlock), lds, st, s->d, ra, d_rgb_sum, (unsigned long long*)d_counters);
-    else
-        hipLaunchKernelGGL(k_render<RRT_AABB_TIGHT>, dim3(grid), dim3(kBlock), lds, st, s->d, ra, d_rgb_sum, (unsigned long long*)d_counters);
-    HIP_TRY(hipGetLastError());
+    // compiled variants: plain (triangles + spheres, constant textures), textured (+ textures, bump maps), full (+ media)
+    constexpr uint32_t kPlain = F_SPHERE, kTextured = F_SPHERE | F_TEX | F_BUMP;
+    const uint32_t need = s->features;
+    unsigned long long* cnt = (unsigned long long*)d_counters;
+    for (uint32_t done = 0; done < plan.spp; done += (uint32_t)per_pass) {
+        ta.n_samples = plan.spp - done < per_pass ? plan.spp - done : (uint32_t)per_pass;
+        ta.first_sample = plan.ta.first_sample + done;
+        const uint64_t items = (uint64_t)((ta.n_samples + kChunk - 1) / kChunk) * ta.n_t8;
+        if (items > 0x7fffffffull) return rrt_set_error(RRT_ERR_LIMIT, "rrt_render: too many work items in one pass");
+        const dim3 grid((unsigned)items);
+#define RRT_LAUNCH(MODE, FEAT) hipLaunchKernelGGL((k_trace<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt)
+        if (p->aabb_mode == RRT_AABB_REFERENCE) {
+            if ((need & ~kPlain) == 0) RRT_LAUNCH(RRT_AABB_REFERENCE, kPlain);
+            else if ((need & ~kTextured) == 0) RRT_LAUNCH(RRT_AABB_REFERENCE, kTextured);
+            else RRT_LAUNCH(RRT_AABB_REFERENCE, F_ALL);
+        } else {
+            if ((need & ~kPlain) == 0) RRT_LAUNCH(RRT_AABB_TIGHT, kPlain);
+            else if ((need & ~kTextured) == 0) RRT_LAUNCH(RRT_AABB_TIGHT, kTextured);
+            else RRT_LAUNCH(RRT_AABB_TIGHT, F_ALL);
+        }
+#undef RRT_LAUNCH
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((frame_floats + 255) / 256)), dim3(256), 0, st, s->slab, ta.n_samples, frame_floats, ta.W,
+                           ta.tiles_x, ta.tile_count, ta.tile_index, done == 0 ? 1 : 0, d_rgb_sum);
+        HIP_TRY(hipGetLastError());
+    }
     return RRT_OK;
 }
 
 int rrt_render(rrt_scene* s, const rrt_render_params* p, float* rgb_sum, rrt_stats* stats) {
-    RenderArgs ra;
-    unsigned grid;
-    int rc = fill_render_args(s, p, &ra, &grid);
+    RenderPlan plan;
+    int rc = plan_render(s, p, &plan);
     if (rc) return rc;
     if (!rgb_sum) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: NULL output");
-    size_t bytes = (size_t)ra.W * ra.H * 3 * sizeof(float);
+    size_t bytes = (size_t)plan.ta.W * plan.ta.H * 3 * sizeof(float);
     float* d_img = nullptr;
     uint64_t* d_cnt = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;

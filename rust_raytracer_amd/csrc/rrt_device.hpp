@@ -188,7 +188,7 @@ RRT_DEV float rng_keyed(const Rng& r, uint32_t depth, uint32_t prim) {
 struct DScene {
     const float4* nodes;      // 2 x float4 per rrt_node
     const float4* slots;      // 3 x float4 per rrt_slot
-    const float4* tri_shade;  // 3 x float4 per rrt_tri_shade
+    const float4* tri_shade;  // 4 x float4 per rrt_tri_shade
     const rrt_sphere* spheres;
     const rrt_medium* media;
     const float4* btris;
@@ -384,6 +384,31 @@ RRT_DEV bool triangle_hit(f3 v0, f3 e1, f3 e2, bool cull, const Ray& r, float t_
     }
     return false;
 }
+// The same test, also returning the determinant and barycentrics it computed; Triangle::get_hit_properties
+// (shape.rs:384-400) recomputes exactly these values from the same inputs, so they can be carried instead.
+RRT_DEV bool triangle_hit_uv(f3 v0, f3 e1, f3 e2, bool cull, const Ray& r, float t_min, float t_max, float* t_out, float* u_out, float* v_out,
+                             float* det_out) {
+    f3 p_vec = cross3(r.d, e2);
+    float det = dot3(e1, p_vec);
+    if (!cull && det > -RRT_EPS && det < RRT_EPS) return false;
+    else if (cull && det < RRT_EPS) return false;
+    float inv_det = 1.0f / det;
+    f3 t_vec = r.o - v0;
+    float u = dot3(t_vec, p_vec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 q_vec = cross3(t_vec, e1);
+    float v = dot3(r.d, q_vec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t_hit = dot3(e2, q_vec) * inv_det;
+    if (t_hit < t_max && t_hit > t_min) {
+        *t_out = t_hit;
+        *u_out = u;
+        *v_out = v;
+        *det_out = det;
+        return true;
+    }
+    return false;
+}
 // &Matrix4 * &Ray (matrix.rs:154-190) with a row-major 3x4
 RRT_DEV Ray xform_ray(const float* m, const Ray& r) {
     Ray o;
@@ -401,6 +426,23 @@ RRT_DEV f3 xform_point(const float* m, f3 p) {
                m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * 1.0f);
 }
 // Sphere::hit (shape.rs:65-85)
+RRT_DEV bool sphere_hit_m(const float* w2l, float radius, const Ray& r, float t_min, float t_max, float* t_out) {
+    Ray lr = xform_ray(w2l, r);
+    f3 oc = lr.o - mk3(0.0f, 0.0f, 0.0f);
+    float a = dot3(lr.d, lr.d);
+    float b = 2.0f * dot3(oc, lr.d);
+    float c = dot3(oc, oc) - (radius * radius);
+    float disc = b * b - 4.0f * a * c;
+    if (disc > 0.0f) {
+        float t_hit = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
+        if (t_hit >= t_max || t_hit <= t_min) t_hit = (-b + __builtin_sqrtf(disc)) / (2.0f * a);
+        if (t_hit < t_max && t_hit > t_min) {
+            *t_out = t_hit;
+            return true;
+        }
+    }
+    return false;
+}
 RRT_DEV bool sphere_hit(const rrt_sphere& s, const Ray& r, float t_min, float t_max, float* t_out) {
     Ray lr = xform_ray(s.w2l, r);
     f3 oc = lr.o - mk3(0.0f, 0.0f, 0.0f);
@@ -479,19 +521,68 @@ RRT_DEV bool aabb_test(f3 bmin, f3 bmax, f3 o, f3 inv, float t_min, float t_max)
     return ex_pad >= lo_pad;
 }
 
+// ---- scene features a kernel variant is compiled for ------------------------------------------------------------------
+// The host picks the smallest variant that covers the scene, so scenes without media / image textures / bump maps do not
+// carry that code (registers, instruction cache) through the inner loop.
+enum : uint32_t {
+    F_SPHERE = 1u,  // sphere primitives (or sphere lights)
+    F_MEDIUM = 2u,  // ConstantMedium primitives and the Isotropic phase function
+    F_TEX = 4u,     // textures other than Constant (needs uv / world point in texture lookups)
+    F_BUMP = 8u,    // bump maps (needs pu, pv)
+    F_ALL = 15u
+};
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const v4f __attribute__((address_space(4))) * cv4p;    // constant address space: wave-uniform addresses load through the scalar cache
+typedef const float __attribute__((address_space(4))) * cf1p;
+
 // ---- closest hit: BVH::hit (aggregate.rs:324-401) with List::hit (aggregate.rs:144-165) in the leaves ------------
 struct Hit {
     int slot;  // -1 = miss
     float t;
+    float u, v, det;  // triangle hits: the values Triangle::hit computed (reused by the hit properties)
 };
+
+// One primitive of a leaf against the ray: updates `h` when it is hit closer than h.t (strict, first visited wins ties).
+template <uint32_t FEAT>
+RRT_DEV void test_slot(const DScene& sc, f3 v0, uint32_t prim, f3 e1, uint32_t info, f3 e2, uint32_t aux, int s, const Ray& r, float t_min,
+                       const Rng& key, uint32_t depth, Hit& h) {
+    const uint32_t kind = RRT_INFO_KIND(info);
+    if (!(FEAT & (F_SPHERE | F_MEDIUM)) || kind == RRT_KIND_TRIANGLE) {
+        float t, u, v, det;
+        if (triangle_hit_uv(v0, e1, e2, (info & RRT_INFO_CULL) != 0, r, t_min, h.t, &t, &u, &v, &det)) {
+            h.t = t;
+            h.slot = s;
+            h.u = u;
+            h.v = v;
+            h.det = det;
+        }
+    } else if ((FEAT & F_SPHERE) && kind == RRT_KIND_SPHERE) {
+        float t;
+        if (sphere_hit(sc.spheres[aux], r, t_min, h.t, &t)) {
+            h.t = t;
+            h.slot = s;
+        }
+    } else if (FEAT & F_MEDIUM) {
+        float t;
+        float xi = rng_keyed(key, depth, prim);
+        if (medium_hit(sc, sc.media[aux], r, t_min, h.t, xi, &t)) {
+            h.t = t;
+            h.slot = s;
+        }
+    }
+}
+
 // `stack` points at this lane's first entry of an LDS array laid out [entry][thread]; `stride` = threads per block.
-template <int AABB_MODE>
+template <int AABB_MODE, uint32_t FEAT>
 RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack, uint32_t stride) {
     Hit h;
     h.slot = -1;
     h.t = t_max;
+    h.u = h.v = h.det = 0.0f;
     if (sc.n_nodes == 0) return h;
     const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const cv4p cslots = (cv4p)(const void*)sc.slots;
     uint32_t sp = 0;
     uint32_t cur = 0;
     for (;;) {
@@ -503,25 +594,38 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
         if (inside) {
             const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
             if (b & RRT_LEAF_FLAG) {
-                const uint32_t count = b & ~RRT_LEAF_FLAG;
-                for (uint32_t k = 0; k < count; ++k) {
-                    const uint32_t s = a + k;
-                    const float4 q0 = sc.slots[3 * s], q1 = sc.slots[3 * s + 1], q2 = sc.slots[3 * s + 2];
-                    const uint32_t info = __float_as_uint(q1.w);
-                    const uint32_t kind = RRT_INFO_KIND(info);
-                    float t;
-                    bool got;
-                    if (kind == RRT_KIND_TRIANGLE) {
-                        got = triangle_hit(xyz(q0), xyz(q1), xyz(q2), (info & RRT_INFO_CULL) != 0, r, t_min, h.t, &t);
-                    } else if (kind == RRT_KIND_SPHERE) {
-                        got = sphere_hit(sc.spheres[__float_as_uint(q2.w)], r, t_min, h.t, &t);
-                    } else {
-                        float xi = rng_keyed(key, depth, __float_as_uint(q0.w));
-                        got = medium_hit(sc, sc.media[__float_as_uint(q2.w)], r, t_min, h.t, xi, &t);
+                const uint32_t ua = __builtin_amdgcn_readfirstlane(a), ub = __builtin_amdgcn_readfirstlane(b);
+                if (__ballot(a != ua || b != ub) == 0ull) {
+                    // Every lane that reached a leaf is in the SAME leaf (always so for the one- and few-leaf trees the
+                    // reference builds for small scenes): walk it with wave-uniform indices, so primitive records come
+                    // through the scalar cache into SGPRs and the kind dispatch is a scalar branch.
+                    const uint32_t count = ub & ~RRT_LEAF_FLAG;
+                    for (uint32_t k = 0; k < count; ++k) {
+                        const uint32_t s = ua + k;
+                        const v4f q0 = cslots[3 * s], q1 = cslots[3 * s + 1], q2 = cslots[3 * s + 2];
+                        const uint32_t info = __float_as_uint(q1.w);
+                        if ((FEAT & F_SPHERE) && RRT_INFO_KIND(info) == RRT_KIND_SPHERE) {
+                            const cf1p sp4 = (cf1p)(const void*)&sc.spheres[__float_as_uint(q2.w)];
+                            float w2l[12];
+#pragma unroll
+                            for (int j = 0; j < 12; ++j) w2l[j] = sp4[j];
+                            float t;
+                            if (sphere_hit_m(w2l, sp4[24], r, t_min, h.t, &t)) {
+                                h.t = t;
+                                h.slot = (int)s;
+                            }
+                        } else {
+                            test_slot<FEAT>(sc, mk3(q0.x, q0.y, q0.z), __float_as_uint(q0.w), mk3(q1.x, q1.y, q1.z), info, mk3(q2.x, q2.y, q2.z),
+                                            __float_as_uint(q2.w), (int)s, r, t_min, key, depth, h);
+                        }
                     }
-                    if (got) {
-                        h.t = t;
-                        h.slot = (int)s;
+                } else {
+                    const uint32_t count = b & ~RRT_LEAF_FLAG;
+                    for (uint32_t k = 0; k < count; ++k) {
+                        const uint32_t s = a + k;
+                        const float4 q0 = sc.slots[3 * s], q1 = sc.slots[3 * s + 1], q2 = sc.slots[3 * s + 2];
+                        test_slot<FEAT>(sc, xyz(q0), __float_as_uint(q0.w), xyz(q1), __float_as_uint(q1.w), xyz(q2), __float_as_uint(q2.w), (int)s, r,
+                                        t_min, key, depth, h);
                     }
                 }
             } else {
@@ -556,11 +660,11 @@ RRT_DEV HitProps sphere_props(const rrt_sphere& s, const Ray& r, float t_hit, bo
     const float one_over_2pi = 1.0f / (2.0f * RRT_PI);  // shape.rs:63
     Ray lr = xform_ray(s.w2l, r);
     f3 lp = point_at(lr, t_hit);
-    f3 hp = lp * (__builtin_fabsf(s.radius) / len3(lp - mk3(0.0f, 0.0f, 0.0f)));
     HitProps h;
     h.p = point_at(r, t_hit);
     h.n = norm3(xform_vec(s.l2w, (lp - mk3(0.0f, 0.0f, 0.0f)) / s.radius));
-    if (want_uv) {  // uv, pu, pv feed textures and bump maps only
+    if (want_uv) {  // uv, pu, pv feed non-constant textures and bump maps only
+        f3 hp = lp * (__builtin_fabsf(s.radius) / len3(lp - mk3(0.0f, 0.0f, 0.0f)));
         float theta = det_asin(clampf(hp.y / s.radius, -1.0f, 1.0f));
         float inv_y_radius = (signum_ref(s.radius) * 1.0f) / __builtin_sqrtf(hp.x * hp.x + hp.z * hp.z);
         f3 pu = mk3(2.0f * RRT_PI * hp.z, 0.0f, -2.0f * RRT_PI * hp.x);
@@ -575,44 +679,59 @@ RRT_DEV HitProps sphere_props(const rrt_sphere& s, const Ray& r, float t_hit, bo
     }
     return h;
 }
-RRT_DEV HitProps triangle_props(f3 v0, f3 e1, f3 e2, const float4& s0, const float4& s1, const float4& s2, const Ray& r, float t_hit) {
-    f3 p_vec = cross3(r.d, e2);
-    float det = dot3(e1, p_vec);
-    f3 normal = norm3(cross3(e1, e2));
+// tri_shade record: s0 = (n.xyz, -), s1 = (uv0, uv1), s2 = (uv2, pu.xy), s3 = (pu.z, pv.xyz); n = normalized(e1 x e2)
+// as Triangle::get_hit_properties forms it (shape.rs:390), computed once on the host with the same operations.
+RRT_DEV HitProps triangle_props(const float4* shade4, const Ray& r, float t_hit, float u, float v, float det, bool want_uv) {
+    const float4 s0 = shade4[0];
+    f3 normal = xyz(s0);
     if (det < 0.0f) normal = -normal;
-    float inv_det = 1.0f / det;
-    f3 t_vec = r.o - v0;
-    float u = dot3(t_vec, p_vec) * inv_det;
-    f3 q_vec = cross3(t_vec, e1);
-    float v = dot3(r.d, q_vec) * inv_det;
-    float w = 1.0f - u - v;
-    // tri_shade: s0 = (uv0.u, uv0.v, uv1.u, uv1.v), s1 = (uv2.u, uv2.v, pu.x, pu.y), s2 = (pu.z, pv.x, pv.y, pv.z)
     HitProps h;
-    h.u = s0.x * u + s0.z * v + s1.x * w;  // uv0 pairs with u, uv1 with v, uv2 with w (shape.rs:407-410)
-    h.v = s0.y * u + s0.w * v + s1.y * w;
-    f3 pu = mk3(s1.z, s1.w, s2.x);
-    if (det < 0.0f) pu = -pu;
     h.p = point_at(r, t_hit);
     h.n = normal;
-    h.pu = pu;
-    h.pv = mk3(s2.y, s2.z, s2.w);
+    if (want_uv) {
+        const float4 s1 = shade4[1], s2 = shade4[2], s3 = shade4[3];
+        float w = 1.0f - u - v;
+        h.u = s1.x * u + s1.z * v + s2.x * w;  // uv0 pairs with u, uv1 with v, uv2 with w (shape.rs:407-410)
+        h.v = s1.y * u + s1.w * v + s2.y * w;
+        f3 pu = mk3(s2.z, s2.w, s3.x);
+        if (det < 0.0f) pu = -pu;
+        h.pu = pu;
+        h.pv = mk3(s3.y, s3.z, s3.w);
+    } else {
+        h.u = h.v = 0.0f;
+        h.pu = h.pv = mk3(0.0f, 0.0f, 0.0f);
+    }
     return h;
 }
-// Shape::get_hit_properties for whatever sits in `slot`; *material receives Shape::get_material.
-RRT_DEV HitProps slot_props(const DScene& sc, int slot, const Ray& r, float t_hit, uint32_t* material) {
-    const float4 q0 = sc.slots[3 * slot], q1 = sc.slots[3 * slot + 1], q2 = sc.slots[3 * slot + 2];
+// Recomputes (u, v, det) the way Triangle::get_hit_properties does (shape.rs:384-400) for callers without a Hit.
+RRT_DEV void triangle_uvdet(f3 v0, f3 e1, f3 e2, const Ray& r, float* u, float* v, float* det) {
+    f3 p_vec = cross3(r.d, e2);
+    float d = dot3(e1, p_vec);
+    float inv_det = 1.0f / d;
+    f3 t_vec = r.o - v0;
+    *u = dot3(t_vec, p_vec) * inv_det;
+    f3 q_vec = cross3(t_vec, e1);
+    *v = dot3(r.d, q_vec) * inv_det;
+    *det = d;
+}
+// Shape::get_hit_properties for whatever sits in `hit.slot`; *material receives Shape::get_material.
+template <uint32_t FEAT>
+RRT_DEV HitProps slot_props(const DScene& sc, const Hit& hit, const Ray& r, uint32_t* material) {
+    const int slot = hit.slot;
+    const float4 q1 = sc.slots[3 * slot + 1];
     const uint32_t info = __float_as_uint(q1.w);
     *material = RRT_INFO_MATERIAL(info);
     const uint32_t kind = RRT_INFO_KIND(info);
-    if (kind == RRT_KIND_TRIANGLE) {
-        return triangle_props(xyz(q0), xyz(q1), xyz(q2), sc.tri_shade[3 * slot], sc.tri_shade[3 * slot + 1], sc.tri_shade[3 * slot + 2], r, t_hit);
-    }
-    if (kind == RRT_KIND_SPHERE) return sphere_props(sc.spheres[__float_as_uint(q2.w)], r, t_hit, true);
-    const rrt_medium m = sc.media[__float_as_uint(q2.w)];  // volume.rs:104-106
-    if (m.boundary_kind == RRT_KIND_SPHERE) return sphere_props(sc.spheres[m.boundary_index], r, t_hit, true);
+    const bool want_uv = (FEAT & (F_TEX | F_BUMP)) != 0;
+    if (!(FEAT & (F_SPHERE | F_MEDIUM)) || kind == RRT_KIND_TRIANGLE) return triangle_props(sc.tri_shade + 4 * slot, r, hit.t, hit.u, hit.v, hit.det, want_uv);
+    const uint32_t aux = __float_as_uint(sc.slots[3 * slot + 2].w);
+    if ((FEAT & F_SPHERE) && kind == RRT_KIND_SPHERE) return sphere_props(sc.spheres[aux], r, hit.t, want_uv);
+    const rrt_medium m = sc.media[aux];  // volume.rs:104-106
+    if (m.boundary_kind == RRT_KIND_SPHERE) return sphere_props(sc.spheres[m.boundary_index], r, hit.t, want_uv);
     const uint32_t bi = m.boundary_index;
-    return triangle_props(xyz(sc.btris[3 * bi]), xyz(sc.btris[3 * bi + 1]), xyz(sc.btris[3 * bi + 2]), sc.btri_shade[3 * bi],
-                          sc.btri_shade[3 * bi + 1], sc.btri_shade[3 * bi + 2], r, t_hit);
+    float u, v, det;
+    triangle_uvdet(xyz(sc.btris[3 * bi]), xyz(sc.btris[3 * bi + 1]), xyz(sc.btris[3 * bi + 2]), r, &u, &v, &det);
+    return triangle_props(sc.btri_shade + 4 * bi, r, hit.t, u, v, det, want_uv);
 }
 
 // ---- light mixture (pdf.rs:85-128; shape.rs:141-166, 441-471) -----------------------------------------------------------
@@ -634,20 +753,6 @@ RRT_DEV float light_pdf(const DScene& sc, const rrt_light& l, const Ray& r) {
     float cosine = __builtin_fabsf(dot3(r.d, ld3(l.nrm)) / len3(r.d));
     return dist_squared / (cosine * l.area);
 }
-RRT_DEV f3 light_sample(const DScene& sc, const rrt_light& l, f3 from, Rng& g) {
-    if (l.kind == RRT_KIND_SPHERE) {  // Sphere::random_dir_towards
-        const rrt_sphere& s = sc.spheres[l.index];
-        f3 local_point = xform_point(s.w2l, from);
-        f3 dir = mk3(0.0f, 0.0f, 0.0f) - local_point;
-        f3 d = random_to_sphere(g, s.radius, sqlen3(dir));
-        return xform_vec(s.l2w, onb_local(dir, d));
-    }
-    // Triangle::random_dir_towards
-    float r1 = rng_f32(g);
-    float r2 = rng_f32(g);
-    f3 random_point = ld3(l.v0) * (1.0f - __builtin_sqrtf(r1)) + ld3(l.v1) * (__builtin_sqrtf(r1) * (1.0f - r2)) + ld3(l.v2) * (r2 * __builtin_sqrtf(r1));
-    return random_point - from;
-}
 RRT_DEV float mixture_value(const DScene& sc, const Ray& r) {  // Mixture::value
     float weight = 1.0f / (float)sc.n_lights;
     float sum = 0.0f;
@@ -657,6 +762,55 @@ RRT_DEV float mixture_value(const DScene& sc, const Ray& r) {  // Mixture::value
 RRT_DEV float cosine_value(f3 normal, const Ray& r) {  // pdf.rs:51-58
     float cosine = dot3(norm3(r.d), normal);
     return cosine < 0.0f ? 0.0f : cosine / RRT_PI;
+}
+// The scattered direction of the PDF branch of trace (aggregate.rs:58-77): pair_generate (pdf.rs:121-128) picks the light
+// mixture or the cosine lobe; Mixture::generate (pdf.rs:109-114) picks a member.  Sphere lights (random_to_sphere) and the
+// cosine lobe (random_cosine_direction) are both "two draws, one sincos, one orthonormal basis", so they share that code:
+// only the basis axis and the (z, sin-radius) pair differ.  Draw order is the reference's: [pair], [member], r1, r2.
+RRT_DEV f3 sample_scatter_direction(const DScene& sc, f3 n, f3 from, Rng& g) {
+    bool towards_light = false;
+    uint32_t k = 0;
+    if (sc.n_lights > 0) {
+        float xi = rng_f32(g);
+        if (xi < 0.5f) {
+            towards_light = true;
+            k = rng_index(g, sc.n_lights);
+        }
+    }
+    float r1 = rng_f32(g);
+    float r2 = rng_f32(g);
+    bool tri_light = false;
+    bool sphere_light = false;
+    if (towards_light) {
+        uint32_t kind = sc.lights[k].kind;
+        tri_light = kind == RRT_KIND_TRIANGLE;
+        sphere_light = !tri_light;
+    }
+    if (tri_light) {  // Triangle::random_dir_towards
+        const rrt_light& l = sc.lights[k];
+        f3 random_point = ld3(l.v0) * (1.0f - __builtin_sqrtf(r1)) + ld3(l.v1) * (__builtin_sqrtf(r1) * (1.0f - r2)) + ld3(l.v2) * (r2 * __builtin_sqrtf(r1));
+        return random_point - from;
+    }
+    f3 axis = n;
+    float z, rad;  // local direction = (cos(phi) * rad, sin(phi) * rad, z)
+    const rrt_sphere* s = nullptr;
+    if (sphere_light) {  // Sphere::random_dir_towards + random_to_sphere
+        s = &sc.spheres[sc.lights[k].index];
+        f3 local_point = xform_point(s->w2l, from);
+        axis = mk3(0.0f, 0.0f, 0.0f) - local_point;
+        float distance_squared = sqlen3(axis);
+        z = 1.0f + r2 * (__builtin_sqrtf(fmax_ref(1.0f - s->radius * s->radius / distance_squared, 0.0f)) - 1.0f);
+        rad = __builtin_sqrtf(fmax_ref(1.0f - z * z, 0.0f));
+    } else {  // random_cosine_direction
+        z = __builtin_sqrtf(1.0f - r2);
+        rad = __builtin_sqrtf(r2);
+    }
+    float phi = 2.0f * RRT_PI * r1;
+    float sp, cp;
+    det_sincos(phi, &sp, &cp);
+    f3 d = onb_local(axis, mk3(cp * rad, sp * rad, z));
+    if (sphere_light) d = xform_vec(s->l2w, d);
+    return d;
 }
 
 // ---- materials (material.rs:15-54) -----------------------------------------------------------------------------------------
@@ -674,6 +828,13 @@ RRT_DEV float schlick_ref(float cosine, float index) {
     float a2 = a * a;
     float a4 = a2 * a2;
     return r0 + (1.0f - r0) * (a * a4);  // f32::powi(5) = a * ((a*a)*(a*a))
+}
+// Texture::value; without F_TEX every texture is Constant.
+template <uint32_t FEAT>
+RRT_DEV f3 albedo_value(const DScene& sc, int tex, float u, float v, f3 p) {
+    if (FEAT & F_TEX) return texture_value(sc, tex, u, v, p);
+    const rrt_texture& t = sc.textures[tex];
+    return mk3(t.a, t.b, t.c);
 }
 RRT_DEV f3 bump_normal(const DScene& sc, const HitProps& hp, int bump_tex) {
     const float delta = 0.005f;
@@ -708,18 +869,21 @@ RRT_DEV Ray camera_ray(const rrt_camera& c, uint32_t x, uint32_t y, uint32_t W, 
 // One step of aggregate::trace (aggregate.rs:26-104) after the closest-hit query, in loop form: either the path ends
 // with a radiance value (`*radiance`, to be weighted by the throughput) or the ray and throughput are advanced.
 // Returns true when the path ended.
+template <uint32_t FEAT>
 RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, uint32_t depth, uint32_t max_depth, uint32_t bg, f3* radiance) {
     if (!(depth < max_depth && hit.slot >= 0)) {
         *radiance = background(bg, r);
         return true;
     }
     uint32_t mat_id;
-    HitProps hp = slot_props(sc, hit.slot, r, hit.t, &mat_id);
-    hp.u = clampf(hp.u, 0.0f, 1.0f);  // aggregate.rs:31
-    hp.v = clampf(hp.v, 0.0f, 1.0f);
+    HitProps hp = slot_props<FEAT>(sc, hit, r, &mat_id);
+    if (FEAT & (F_TEX | F_BUMP)) {
+        hp.u = clampf(hp.u, 0.0f, 1.0f);  // aggregate.rs:31
+        hp.v = clampf(hp.v, 0.0f, 1.0f);
+    }
     const rrt_material m = sc.materials[mat_id];
     if (m.type == RRT_MAT_DIFFUSE_LIGHT) {  // material.rs:229-231: emission ends the path
-        *radiance = texture_value(sc, m.albedo, hp.u, hp.v, hp.p);
+        *radiance = albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
         return true;
     }
     if (m.type == RRT_MAT_DIELECTRIC) {  // material.rs:172-207
@@ -748,43 +912,35 @@ RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, ui
         r.d = out;
         return false;
     }
-    if (m.type == RRT_MAT_ISOTROPIC) {  // volume.rs:27-35
+    if ((FEAT & F_MEDIUM) && m.type == RRT_MAT_ISOTROPIC) {  // volume.rs:27-35
         f3 out = unit_sphere_random(g);
-        f3 att = texture_value(sc, m.albedo, hp.u, hp.v, hp.p);
+        f3 att = albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
         thr = thr * att;
         r.o = hp.p;
         r.d = out;
         return false;
     }
-    f3 n = m.bump < 0 ? hp.n : bump_normal(sc, hp, m.bump);
+    f3 n = hp.n;
+    if ((FEAT & F_BUMP) && m.bump >= 0) n = bump_normal(sc, hp, m.bump);
     if (m.type == RRT_MAT_METAL) {  // material.rs:145-160
         f3 reflected = reflect_ref(norm3(r.d), n);
         f3 out = reflected + m.param * unit_sphere_random(g);
-        f3 att = texture_value(sc, m.albedo, hp.u, hp.v, hp.p);
+        f3 att = albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
         thr = thr * att;
         r.o = hp.p;
         r.d = out;
         return false;
     }
     // Lambert (material.rs:98-110) + the PDF branch of trace (aggregate.rs:57-90)
-    f3 att = texture_value(sc, m.albedo, hp.u, hp.v, hp.p);
+    f3 att = albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
     Ray scattered;
     scattered.o = hp.p;
+    scattered.d = sample_scatter_direction(sc, n, hp.p, g);
+    const float scatter_pdf = cosine_value(n, scattered);
     float pdf_val;
-    if (sc.n_lights > 0) {
-        float xi = rng_f32(g);  // pair_generate, pdf.rs:121-128
-        if (xi < 0.5f) {
-            uint32_t k = rng_index(g, sc.n_lights);
-            scattered.d = light_sample(sc, sc.lights[k], hp.p, g);
-        } else {
-            scattered.d = onb_local(n, random_cosine_direction(g));
-        }
-        pdf_val = mixture_value(sc, scattered) * 0.5f + cosine_value(n, scattered) * 0.5f;  // pair_value, pdf.rs:117-119
-    } else {
-        scattered.d = onb_local(n, random_cosine_direction(g));
-        pdf_val = cosine_value(n, scattered);
-    }
-    thr = (thr * (att * cosine_value(n, scattered))) / pdf_val;
+    if (sc.n_lights > 0) pdf_val = mixture_value(sc, scattered) * 0.5f + scatter_pdf * 0.5f;  // pair_value, pdf.rs:117-119
+    else pdf_val = scatter_pdf;
+    thr = (thr * (att * scatter_pdf)) / pdf_val;
     r = scattered;
     return false;
 }

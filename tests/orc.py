@@ -68,7 +68,7 @@ def lib():
     L.orc_hit_properties.argtypes = [vp, C.c_uint64, f32p, f32p, i32p, f32p, f32p]
     L.orc_camera_rays.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint64, u32p, u32p, u32p, f32p]
     L.orc_render.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint32,
-                             C.c_uint32, f32p, C.c_void_p]
+                             C.c_uint32, f32p, C.c_void_p, C.c_void_p]
     L.orc_resolve_rgb8.argtypes = [f32p, C.c_uint32, C.c_uint32, C.c_uint32, u8p]
     L.orc_unit_triangle_hit.argtypes = [f32p, f32p, f32p, C.c_int, f32p, f32p, C.c_float, C.c_float, C.POINTER(C.c_float)]
     L.orc_unit_sphere_hit.argtypes = [f32p, f32p, f32p, C.c_float, f32p, f32p, C.c_float, C.c_float, C.POINTER(C.c_float)]
@@ -226,7 +226,8 @@ class OracleScene:
         self.L.orc_camera_rays(self.h, W, H, seed, len(px), px, py, sample, out)
         return out[:, :3].copy(), out[:, 3:].copy()
 
-    def render(self, W=None, H=None, spp=None, first_sample=0, seed=0, bg=BG_BLACK, flags=0, max_depth=-1, threads=None, rows=None):
+    def render(self, W=None, H=None, spp=None, first_sample=0, seed=0, bg=BG_BLACK, flags=0, max_depth=-1, threads=None, rows=None,
+               rays_per_pixel=None):
         W = W or self.width
         H = H or self.height
         spp = spp or self.samples
@@ -234,7 +235,8 @@ class OracleScene:
         y0, y1 = rows if rows else (0, H)
         img = np.zeros((H, W, 3), dtype=np.float32)
         st = np.zeros(4, dtype=np.uint64)
-        self.L.orc_render(self.h, W, H, spp, first_sample, seed, bg, flags, max_depth, threads, y0, y1, img.reshape(-1), st.ctypes.data)
+        self.L.orc_render(self.h, W, H, spp, first_sample, seed, bg, flags, max_depth, threads, y0, y1, img.reshape(-1), st.ctypes.data,
+                          rays_per_pixel.ctypes.data if rays_per_pixel is not None else None)
         return img, st
 
     def texture_values(self, tex, uv, p):

@@ -27,7 +27,7 @@ def test_abi_exports_every_declared_symbol():
 
 
 def test_struct_layouts_match_header_sizes():
-    assert C.sizeof(rrt._Node) == 32 and C.sizeof(rrt._Slot) == 48 and C.sizeof(rrt._TriShade) == 48
+    assert C.sizeof(rrt._Node) == 32 and C.sizeof(rrt._Slot) == 48 and C.sizeof(rrt._TriShade) == 64
     assert C.sizeof(rrt._Sphere) == 128 and C.sizeof(rrt._Medium) == 16 and C.sizeof(rrt._Material) == 16
     assert C.sizeof(rrt._Texture) == 32 and C.sizeof(rrt._Light) == 96 and C.sizeof(rrt._Camera) == 76
 
