@@ -263,6 +263,10 @@ int rrt_resolve_rgb8_device(const float* d_rgb_sum, uint32_t width, uint32_t hei
  *           4 first 8 floats of stream (seed=arg, pixel, sample) for (pixel,sample) -> 8 floats */
 int rrt_probe(rrt_scene*, uint32_t which, uint32_t arg, const void* in, size_t n, float* out);
 
+/* No counterpart in the reference: checks on the current device that the 3-instruction reciprocal the triangle test uses
+ * (shape.rs:354 `1.0 / determinant`) equals IEEE division for every one of the 2^32 float bit patterns. */
+int rrt_selftest_reciprocal(uint64_t* mismatches);
+
 const char* rrt_last_error(void);
 const char* rrt_version(void);
 

@@ -130,6 +130,7 @@ def lib():
     L.rrt_resolve_rgb8.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.rrt_resolve_rgb8_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.rrt_probe.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp]
+    L.rrt_selftest_reciprocal.argtypes = [C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -336,6 +337,13 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+def selftest_reciprocal():
+    """Number of float bit patterns (of all 2^32) on which the kernel's fast reciprocal differs from IEEE division."""
+    n = C.c_uint64(0)
+    _check(lib().rrt_selftest_reciprocal(C.byref(n)))
+    return n.value
 
 
 def resolve_rgb8(rgb_sum, spp):

@@ -209,6 +209,19 @@ __global__ void k_probe(DScene sc, uint32_t which, uint32_t arg, uint32_t W, uin
     }
 }
 
+// Exhaustive check of exact_rcp against IEEE division over all 2^32 bit patterns.
+__global__ void k_selftest_rcp(unsigned long long* __restrict__ mismatches) {
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    unsigned long long bad = 0;
+    for (uint64_t b = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; b < (1ull << 32); b += stride) {
+        const float x = __uint_as_float((uint32_t)b);
+        const float ref = 1.0f / x;
+        const float got = exact_rcp(x);
+        if (__float_as_uint(ref) != __float_as_uint(got) && !(ref != ref && got != got)) ++bad;
+    }
+    if (bad) atomicAdd(mismatches, bad);
+}
+
 #define HIP_TRY(expr)                                                                                   \
     do {                                                                                                \
         hipError_t e_ = (expr);                                                                         \
@@ -577,6 +590,20 @@ int rrt_resolve_rgb8(const float* rgb_sum, uint32_t W, uint32_t H, uint32_t spp,
     if (rc) { cleanup(); return rc; }
     TRY2(hipDeviceSynchronize());
     TRY2(hipMemcpy(out, d_out, n, hipMemcpyDeviceToHost));
+    cleanup();
+    return RRT_OK;
+}
+
+int rrt_selftest_reciprocal(uint64_t* mismatches) {
+    if (!mismatches) return rrt_set_error(RRT_ERR_INVALID, "rrt_selftest_reciprocal: NULL argument");
+    unsigned long long* d = nullptr;
+    auto cleanup = [&]() { (void)hipFree(d); };
+    TRY2(hipMalloc((void**)&d, 8));
+    TRY2(hipMemset(d, 0, 8));
+    hipLaunchKernelGGL(k_selftest_rcp, dim3(65536), dim3(256), 0, nullptr, d);
+    TRY2(hipGetLastError());
+    TRY2(hipDeviceSynchronize());
+    TRY2(hipMemcpy(mismatches, d, 8, hipMemcpyDeviceToHost));
     cleanup();
     return RRT_OK;
 }

@@ -184,6 +184,22 @@ RRT_DEV float rng_keyed(const Rng& r, uint32_t depth, uint32_t prim) {
     return u32_to_unit(mix32(r.s0 ^ h));
 }
 
+// ---- read-only scene data is addressed through the constant address space ---------------------------
+// Loads whose address is wave-uniform then go through the scalar cache into SGPRs (no VGPRs, no per-lane address
+// arithmetic); loads with per-lane addresses become ordinary vector loads that the compiler may hoist and merge,
+// because constant-address-space memory cannot be written by the kernel.
+#define RRT_CONST_AS __attribute__((address_space(4)))
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const v4f RRT_CONST_AS* cv4p;
+typedef const float RRT_CONST_AS* cf1p;
+typedef const rrt_sphere RRT_CONST_AS* csphere_p;
+typedef const rrt_medium RRT_CONST_AS* cmedium_p;
+typedef const rrt_material RRT_CONST_AS* cmaterial_p;
+typedef const rrt_texture RRT_CONST_AS* ctexture_p;
+typedef const rrt_light RRT_CONST_AS* clight_p;
+RRT_DEV f3 ld3(cf1p p) { return f3{p[0], p[1], p[2]}; }
+RRT_DEV f3 xyz(v4f q) { return f3{q.x, q.y, q.z}; }
+
 // ---- device view of the scene ----------------------------------------------------------------------
 struct DScene {
     const float4* nodes;      // 2 x float4 per rrt_node
@@ -199,6 +215,17 @@ struct DScene {
     const rrt_light* lights;
     uint32_t n_nodes, n_slots, n_lights, is_list;
     rrt_camera cam;
+
+    RRT_DEV cv4p c_nodes() const { return (cv4p)(const void*)nodes; }
+    RRT_DEV cv4p c_slots() const { return (cv4p)(const void*)slots; }
+    RRT_DEV cv4p c_tri_shade() const { return (cv4p)(const void*)tri_shade; }
+    RRT_DEV cv4p c_btris() const { return (cv4p)(const void*)btris; }
+    RRT_DEV cv4p c_btri_shade() const { return (cv4p)(const void*)btri_shade; }
+    RRT_DEV csphere_p c_spheres() const { return (csphere_p)(const void*)spheres; }
+    RRT_DEV cmedium_p c_media() const { return (cmedium_p)(const void*)media; }
+    RRT_DEV cmaterial_p c_materials() const { return (cmaterial_p)(const void*)materials; }
+    RRT_DEV ctexture_p c_textures() const { return (ctexture_p)(const void*)textures; }
+    RRT_DEV clight_p c_lights() const { return (clight_p)(const void*)lights; }
 };
 
 struct Ray {
@@ -328,7 +355,8 @@ RRT_DEV float perlin_turbulence(f3 p, uint32_t depth, float omega) {  // utils.r
 // ---- textures (texture.rs:61-179) ------------------------------------------------------------------------
 RRT_DEV f3 texture_value(const DScene& sc, int tex, float u, float v, f3 p) {
     for (;;) {
-        const rrt_texture t = sc.textures[tex];
+        const ctexture_p tp = sc.c_textures() + tex;
+        struct { uint32_t type; float a, b, c; uint32_t u0, u1, u2, u3; } t = {tp->type, tp->a, tp->b, tp->c, tp->u0, tp->u1, tp->u2, tp->u3};
         switch (t.type) {
             case RRT_TEX_CONSTANT:
                 return mk3(t.a, t.b, t.c);
@@ -363,6 +391,20 @@ RRT_DEV float texture_bump_value(const DScene& sc, int tex, float u, float v, f3
     return (b.x + b.y + b.z) / 3.0f;
 }
 
+// ---- exact reciprocal ------------------------------------------------------------------------------------------
+// 1.0f / x, correctly rounded, in 3 instructions for 2^-100 <= |x| <= 2^100: the hardware reciprocal estimate plus one
+// fused Newton step.  Equality with IEEE division was checked on gfx950 for every float in that range
+// (rrt_selftest_reciprocal repeats the exhaustive check); outside it the full division sequence runs.
+RRT_DEV float rcp_newton(float x) {
+    float r0 = __builtin_amdgcn_rcpf(x);
+    float e = __builtin_fmaf(-x, r0, 1.0f);
+    return __builtin_fmaf(e, r0, r0);
+}
+RRT_DEV float exact_rcp(float x) {
+    if (__builtin_fabsf(x) >= 7.888609052210118e-31f && __builtin_fabsf(x) <= 1.2676506002282294e30f) return rcp_newton(x);
+    return 1.0f / x;
+}
+
 // ---- primitives ----------------------------------------------------------------------------------------------
 // Triangle::hit (shape.rs:335-372) on a slot holding v0, e1 = v1 - v0, e2 = v2 - v0.
 RRT_DEV bool triangle_hit(f3 v0, f3 e1, f3 e2, bool cull, const Ray& r, float t_min, float t_max, float* t_out) {
@@ -370,7 +412,7 @@ RRT_DEV bool triangle_hit(f3 v0, f3 e1, f3 e2, bool cull, const Ray& r, float t_
     float det = dot3(e1, p_vec);
     if (!cull && det > -RRT_EPS && det < RRT_EPS) return false;
     else if (cull && det < RRT_EPS) return false;
-    float inv_det = 1.0f / det;
+    float inv_det = exact_rcp(det);
     f3 t_vec = r.o - v0;
     float u = dot3(t_vec, p_vec) * inv_det;
     if (u < 0.0f || u > 1.0f) return false;
@@ -392,7 +434,7 @@ RRT_DEV bool triangle_hit_uv(f3 v0, f3 e1, f3 e2, bool cull, const Ray& r, float
     float det = dot3(e1, p_vec);
     if (!cull && det > -RRT_EPS && det < RRT_EPS) return false;
     else if (cull && det < RRT_EPS) return false;
-    float inv_det = 1.0f / det;
+    float inv_det = exact_rcp(det);
     f3 t_vec = r.o - v0;
     float u = dot3(t_vec, p_vec) * inv_det;
     if (u < 0.0f || u > 1.0f) return false;
@@ -410,7 +452,8 @@ RRT_DEV bool triangle_hit_uv(f3 v0, f3 e1, f3 e2, bool cull, const Ray& r, float
     return false;
 }
 // &Matrix4 * &Ray (matrix.rs:154-190) with a row-major 3x4
-RRT_DEV Ray xform_ray(const float* m, const Ray& r) {
+template <class P>
+RRT_DEV Ray xform_ray(P m, const Ray& r) {
     Ray o;
     o.o = mk3(m[0] * r.o.x + m[1] * r.o.y + m[2] * r.o.z + m[3] * 1.0f, m[4] * r.o.x + m[5] * r.o.y + m[6] * r.o.z + m[7] * 1.0f,
               m[8] * r.o.x + m[9] * r.o.y + m[10] * r.o.z + m[11] * 1.0f);
@@ -418,15 +461,18 @@ RRT_DEV Ray xform_ray(const float* m, const Ray& r) {
               m[8] * r.d.x + m[9] * r.d.y + m[10] * r.d.z);
     return o;
 }
-RRT_DEV f3 xform_vec(const float* m, f3 v) {
+template <class P>
+RRT_DEV f3 xform_vec(P m, f3 v) {
     return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
 }
-RRT_DEV f3 xform_point(const float* m, f3 p) {
+template <class P>
+RRT_DEV f3 xform_point(P m, f3 p) {
     return mk3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3] * 1.0f, m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7] * 1.0f,
                m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * 1.0f);
 }
 // Sphere::hit (shape.rs:65-85)
-RRT_DEV bool sphere_hit_m(const float* w2l, float radius, const Ray& r, float t_min, float t_max, float* t_out) {
+template <class P>
+RRT_DEV bool sphere_hit_m(P w2l, float radius, const Ray& r, float t_min, float t_max, float* t_out) {
     Ray lr = xform_ray(w2l, r);
     f3 oc = lr.o - mk3(0.0f, 0.0f, 0.0f);
     float a = dot3(lr.d, lr.d);
@@ -443,31 +489,18 @@ RRT_DEV bool sphere_hit_m(const float* w2l, float radius, const Ray& r, float t_
     }
     return false;
 }
-RRT_DEV bool sphere_hit(const rrt_sphere& s, const Ray& r, float t_min, float t_max, float* t_out) {
-    Ray lr = xform_ray(s.w2l, r);
-    f3 oc = lr.o - mk3(0.0f, 0.0f, 0.0f);
-    float a = dot3(lr.d, lr.d);
-    float b = 2.0f * dot3(oc, lr.d);
-    float c = dot3(oc, oc) - (s.radius * s.radius);
-    float disc = b * b - 4.0f * a * c;
-    if (disc > 0.0f) {
-        float t_hit = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
-        if (t_hit >= t_max || t_hit <= t_min) t_hit = (-b + __builtin_sqrtf(disc)) / (2.0f * a);
-        if (t_hit < t_max && t_hit > t_min) {
-            *t_out = t_hit;
-            return true;
-        }
-    }
-    return false;
+RRT_DEV bool sphere_hit(csphere_p s, const Ray& r, float t_min, float t_max, float* t_out) {
+    return sphere_hit_m((cf1p)s->w2l, s->radius, r, t_min, t_max, t_out);
 }
 // The boundary shape of a medium: a sphere or a single triangle.
-RRT_DEV bool boundary_hit(const DScene& sc, const rrt_medium& m, const Ray& r, float t_min, float t_max, float* t_out) {
-    if (m.boundary_kind == RRT_KIND_SPHERE) return sphere_hit(sc.spheres[m.boundary_index], r, t_min, t_max, t_out);
-    float4 q0 = sc.btris[3 * m.boundary_index], q1 = sc.btris[3 * m.boundary_index + 1], q2 = sc.btris[3 * m.boundary_index + 2];
+RRT_DEV bool boundary_hit(const DScene& sc, cmedium_p m, const Ray& r, float t_min, float t_max, float* t_out) {
+    if (m->boundary_kind == RRT_KIND_SPHERE) return sphere_hit(sc.c_spheres() + m->boundary_index, r, t_min, t_max, t_out);
+    const cv4p bt = sc.c_btris() + 3 * m->boundary_index;
+    const v4f q0 = bt[0], q1 = bt[1], q2 = bt[2];
     return triangle_hit(xyz(q0), xyz(q1), xyz(q2), (__float_as_uint(q1.w) & RRT_INFO_CULL) != 0, r, t_min, t_max, t_out);
 }
 // ConstantMedium::hit (volume.rs:65-102); xi is the uniform draw of line 95
-RRT_DEV bool medium_hit(const DScene& sc, const rrt_medium& m, const Ray& r, float t_min, float t_max, float xi, float* t_out) {
+RRT_DEV bool medium_hit(const DScene& sc, cmedium_p m, const Ray& r, float t_min, float t_max, float xi, float* t_out) {
     float t1, t2;
     if (!boundary_hit(sc, m, r, -RRT_T_MAX, RRT_T_MAX, &t1)) return false;
     if (!boundary_hit(sc, m, r, t1 + RRT_EPS, RRT_T_MAX, &t2)) return false;
@@ -476,7 +509,7 @@ RRT_DEV bool medium_hit(const DScene& sc, const rrt_medium& m, const Ray& r, flo
     if (t1 >= t2) return false;
     if (t1 < 0.0f) t1 = 0.0f;
     float distance_inside = (t2 - t1) * len3(r.d);
-    float hit_dist = (-1.0f / m.density) * det_log(xi);
+    float hit_dist = (-1.0f / m->density) * det_log(xi);
     if (hit_dist > distance_inside) return false;
     *t_out = t1 + (hit_dist / len3(r.d));
     return true;
@@ -532,9 +565,6 @@ enum : uint32_t {
     F_ALL = 15u
 };
 
-typedef float v4f __attribute__((ext_vector_type(4)));
-typedef const v4f __attribute__((address_space(4))) * cv4p;    // constant address space: wave-uniform addresses load through the scalar cache
-typedef const float __attribute__((address_space(4))) * cf1p;
 
 // ---- closest hit: BVH::hit (aggregate.rs:324-401) with List::hit (aggregate.rs:144-165) in the leaves ------------
 struct Hit {
@@ -559,14 +589,14 @@ RRT_DEV void test_slot(const DScene& sc, f3 v0, uint32_t prim, f3 e1, uint32_t i
         }
     } else if ((FEAT & F_SPHERE) && kind == RRT_KIND_SPHERE) {
         float t;
-        if (sphere_hit(sc.spheres[aux], r, t_min, h.t, &t)) {
+        if (sphere_hit(sc.c_spheres() + aux, r, t_min, h.t, &t)) {
             h.t = t;
             h.slot = s;
         }
     } else if (FEAT & F_MEDIUM) {
         float t;
         float xi = rng_keyed(key, depth, prim);
-        if (medium_hit(sc, sc.media[aux], r, t_min, h.t, xi, &t)) {
+        if (medium_hit(sc, sc.c_media() + aux, r, t_min, h.t, xi, &t)) {
             h.t = t;
             h.slot = s;
         }
@@ -582,12 +612,13 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
     h.u = h.v = h.det = 0.0f;
     if (sc.n_nodes == 0) return h;
     const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-    const cv4p cslots = (cv4p)(const void*)sc.slots;
+    const cv4p cslots = sc.c_slots();
+    const cv4p cnodes = sc.c_nodes();
     uint32_t sp = 0;
     uint32_t cur = 0;
     for (;;) {
-        const float4 n0 = sc.nodes[2 * cur];
-        const float4 n1 = sc.nodes[2 * cur + 1];
+        const v4f n0 = cnodes[2 * cur];
+        const v4f n1 = cnodes[2 * cur + 1];
         bool inside;
         if (sc.is_list) inside = true;
         else inside = aabb_test<AABB_MODE>(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
@@ -605,12 +636,8 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
                         const v4f q0 = cslots[3 * s], q1 = cslots[3 * s + 1], q2 = cslots[3 * s + 2];
                         const uint32_t info = __float_as_uint(q1.w);
                         if ((FEAT & F_SPHERE) && RRT_INFO_KIND(info) == RRT_KIND_SPHERE) {
-                            const cf1p sp4 = (cf1p)(const void*)&sc.spheres[__float_as_uint(q2.w)];
-                            float w2l[12];
-#pragma unroll
-                            for (int j = 0; j < 12; ++j) w2l[j] = sp4[j];
                             float t;
-                            if (sphere_hit_m(w2l, sp4[24], r, t_min, h.t, &t)) {
+                            if (sphere_hit(sc.c_spheres() + __float_as_uint(q2.w), r, t_min, h.t, &t)) {
                                 h.t = t;
                                 h.slot = (int)s;
                             }
@@ -623,7 +650,7 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
                     const uint32_t count = b & ~RRT_LEAF_FLAG;
                     for (uint32_t k = 0; k < count; ++k) {
                         const uint32_t s = a + k;
-                        const float4 q0 = sc.slots[3 * s], q1 = sc.slots[3 * s + 1], q2 = sc.slots[3 * s + 2];
+                        const v4f q0 = cslots[3 * s], q1 = cslots[3 * s + 1], q2 = cslots[3 * s + 2];
                         test_slot<FEAT>(sc, xyz(q0), __float_as_uint(q0.w), xyz(q1), __float_as_uint(q1.w), xyz(q2), __float_as_uint(q2.w), (int)s, r,
                                         t_min, key, depth, h);
                     }
@@ -656,8 +683,9 @@ RRT_DEV float signum_ref(float f) {  // f32::signum
     if (f != f) return f;
     return (__float_as_uint(f) >> 31) ? -1.0f : 1.0f;
 }
-RRT_DEV HitProps sphere_props(const rrt_sphere& s, const Ray& r, float t_hit, bool want_uv) {
+RRT_DEV HitProps sphere_props(csphere_p sp, const Ray& r, float t_hit, bool want_uv) {
     const float one_over_2pi = 1.0f / (2.0f * RRT_PI);  // shape.rs:63
+    struct { cf1p w2l, l2w; float radius; } s = {(cf1p)sp->w2l, (cf1p)sp->l2w, sp->radius};
     Ray lr = xform_ray(s.w2l, r);
     f3 lp = point_at(lr, t_hit);
     HitProps h;
@@ -681,15 +709,15 @@ RRT_DEV HitProps sphere_props(const rrt_sphere& s, const Ray& r, float t_hit, bo
 }
 // tri_shade record: s0 = (n.xyz, -), s1 = (uv0, uv1), s2 = (uv2, pu.xy), s3 = (pu.z, pv.xyz); n = normalized(e1 x e2)
 // as Triangle::get_hit_properties forms it (shape.rs:390), computed once on the host with the same operations.
-RRT_DEV HitProps triangle_props(const float4* shade4, const Ray& r, float t_hit, float u, float v, float det, bool want_uv) {
-    const float4 s0 = shade4[0];
+RRT_DEV HitProps triangle_props(cv4p shade4, const Ray& r, float t_hit, float u, float v, float det, bool want_uv) {
+    const v4f s0 = shade4[0];
     f3 normal = xyz(s0);
     if (det < 0.0f) normal = -normal;
     HitProps h;
     h.p = point_at(r, t_hit);
     h.n = normal;
     if (want_uv) {
-        const float4 s1 = shade4[1], s2 = shade4[2], s3 = shade4[3];
+        const v4f s1 = shade4[1], s2 = shade4[2], s3 = shade4[3];
         float w = 1.0f - u - v;
         h.u = s1.x * u + s1.z * v + s2.x * w;  // uv0 pairs with u, uv1 with v, uv2 with w (shape.rs:407-410)
         h.v = s1.y * u + s1.w * v + s2.y * w;
@@ -718,45 +746,48 @@ RRT_DEV void triangle_uvdet(f3 v0, f3 e1, f3 e2, const Ray& r, float* u, float* 
 template <uint32_t FEAT>
 RRT_DEV HitProps slot_props(const DScene& sc, const Hit& hit, const Ray& r, uint32_t* material) {
     const int slot = hit.slot;
-    const float4 q1 = sc.slots[3 * slot + 1];
-    const uint32_t info = __float_as_uint(q1.w);
+    const cv4p cslots = sc.c_slots();
+    const uint32_t info = __float_as_uint(cslots[3 * slot + 1].w);
     *material = RRT_INFO_MATERIAL(info);
     const uint32_t kind = RRT_INFO_KIND(info);
     const bool want_uv = (FEAT & (F_TEX | F_BUMP)) != 0;
-    if (!(FEAT & (F_SPHERE | F_MEDIUM)) || kind == RRT_KIND_TRIANGLE) return triangle_props(sc.tri_shade + 4 * slot, r, hit.t, hit.u, hit.v, hit.det, want_uv);
-    const uint32_t aux = __float_as_uint(sc.slots[3 * slot + 2].w);
-    if ((FEAT & F_SPHERE) && kind == RRT_KIND_SPHERE) return sphere_props(sc.spheres[aux], r, hit.t, want_uv);
-    const rrt_medium m = sc.media[aux];  // volume.rs:104-106
-    if (m.boundary_kind == RRT_KIND_SPHERE) return sphere_props(sc.spheres[m.boundary_index], r, hit.t, want_uv);
-    const uint32_t bi = m.boundary_index;
+    if (!(FEAT & (F_SPHERE | F_MEDIUM)) || kind == RRT_KIND_TRIANGLE) return triangle_props(sc.c_tri_shade() + 4 * slot, r, hit.t, hit.u, hit.v, hit.det, want_uv);
+    const uint32_t aux = __float_as_uint(cslots[3 * slot + 2].w);
+    if ((FEAT & F_SPHERE) && kind == RRT_KIND_SPHERE) return sphere_props(sc.c_spheres() + aux, r, hit.t, want_uv);
+    const cmedium_p m = sc.c_media() + aux;  // volume.rs:104-106
+    if (m->boundary_kind == RRT_KIND_SPHERE) return sphere_props(sc.c_spheres() + m->boundary_index, r, hit.t, want_uv);
+    const uint32_t bi = m->boundary_index;
+    const cv4p bt = sc.c_btris() + 3 * bi;
     float u, v, det;
-    triangle_uvdet(xyz(sc.btris[3 * bi]), xyz(sc.btris[3 * bi + 1]), xyz(sc.btris[3 * bi + 2]), r, &u, &v, &det);
-    return triangle_props(sc.btri_shade + 4 * bi, r, hit.t, u, v, det, want_uv);
+    triangle_uvdet(xyz(bt[0]), xyz(bt[1]), xyz(bt[2]), r, &u, &v, &det);
+    return triangle_props(sc.c_btri_shade() + 4 * bi, r, hit.t, u, v, det, want_uv);
 }
 
 // ---- light mixture (pdf.rs:85-128; shape.rs:141-166, 441-471) -----------------------------------------------------------
-RRT_DEV float light_pdf(const DScene& sc, const rrt_light& l, const Ray& r) {
-    if (l.kind == RRT_KIND_SPHERE) {  // Sphere::pdf
-        const rrt_sphere& s = sc.spheres[l.index];
+RRT_DEV float light_pdf(const DScene& sc, clight_p l, const Ray& r) {
+    if (l->kind == RRT_KIND_SPHERE) {  // Sphere::pdf
+        const csphere_p s = sc.c_spheres() + l->index;
         float t;
         if (!sphere_hit(s, r, RRT_T_MIN, RRT_T_MAX, &t)) return 0.0f;
-        Ray lr = xform_ray(s.w2l, r);
-        float cos_theta_max = __builtin_sqrtf(fmax_ref(1.0f - s.radius * s.radius / sqlen3(mk3(0.0f, 0.0f, 0.0f) - lr.o), 0.0f));
+        Ray lr = xform_ray((cf1p)s->w2l, r);
+        const float radius = s->radius;
+        float cos_theta_max = __builtin_sqrtf(fmax_ref(1.0f - radius * radius / sqlen3(mk3(0.0f, 0.0f, 0.0f) - lr.o), 0.0f));
         float solid_angle = 2.0f * RRT_PI * (1.0f - cos_theta_max);
         return 1.0f / solid_angle;
     }
     // Triangle::pdf
     float t_hit;
-    if (!triangle_hit(ld3(l.v0), ld3(l.e1), ld3(l.e2), l.cull != 0, r, RRT_T_MIN, RRT_T_MAX, &t_hit)) return 0.0f;
+    if (!triangle_hit(ld3((cf1p)l->v0), ld3((cf1p)l->e1), ld3((cf1p)l->e2), l->cull != 0, r, RRT_T_MIN, RRT_T_MAX, &t_hit)) return 0.0f;
     float dist_squared = t_hit * t_hit * sqlen3(r.d);
     // the hit normal is +-nrm; only |cos| is used, and negation is exact
-    float cosine = __builtin_fabsf(dot3(r.d, ld3(l.nrm)) / len3(r.d));
-    return dist_squared / (cosine * l.area);
+    float cosine = __builtin_fabsf(dot3(r.d, ld3((cf1p)l->nrm)) / len3(r.d));
+    return dist_squared / (cosine * l->area);
 }
 RRT_DEV float mixture_value(const DScene& sc, const Ray& r) {  // Mixture::value
     float weight = 1.0f / (float)sc.n_lights;
     float sum = 0.0f;
-    for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * light_pdf(sc, sc.lights[i], r);
+    const clight_p lights = sc.c_lights();
+    for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * light_pdf(sc, lights + i, r);
     return sum;
 }
 RRT_DEV float cosine_value(f3 normal, const Ray& r) {  // pdf.rs:51-58
@@ -782,24 +813,26 @@ RRT_DEV f3 sample_scatter_direction(const DScene& sc, f3 n, f3 from, Rng& g) {
     bool tri_light = false;
     bool sphere_light = false;
     if (towards_light) {
-        uint32_t kind = sc.lights[k].kind;
+        uint32_t kind = sc.c_lights()[k].kind;
         tri_light = kind == RRT_KIND_TRIANGLE;
         sphere_light = !tri_light;
     }
     if (tri_light) {  // Triangle::random_dir_towards
-        const rrt_light& l = sc.lights[k];
-        f3 random_point = ld3(l.v0) * (1.0f - __builtin_sqrtf(r1)) + ld3(l.v1) * (__builtin_sqrtf(r1) * (1.0f - r2)) + ld3(l.v2) * (r2 * __builtin_sqrtf(r1));
+        const clight_p l = sc.c_lights() + k;
+        f3 random_point = ld3((cf1p)l->v0) * (1.0f - __builtin_sqrtf(r1)) + ld3((cf1p)l->v1) * (__builtin_sqrtf(r1) * (1.0f - r2)) +
+                          ld3((cf1p)l->v2) * (r2 * __builtin_sqrtf(r1));
         return random_point - from;
     }
     f3 axis = n;
     float z, rad;  // local direction = (cos(phi) * rad, sin(phi) * rad, z)
-    const rrt_sphere* s = nullptr;
+    csphere_p s = sc.c_spheres();
     if (sphere_light) {  // Sphere::random_dir_towards + random_to_sphere
-        s = &sc.spheres[sc.lights[k].index];
-        f3 local_point = xform_point(s->w2l, from);
+        s = sc.c_spheres() + sc.c_lights()[k].index;
+        f3 local_point = xform_point((cf1p)s->w2l, from);
         axis = mk3(0.0f, 0.0f, 0.0f) - local_point;
         float distance_squared = sqlen3(axis);
-        z = 1.0f + r2 * (__builtin_sqrtf(fmax_ref(1.0f - s->radius * s->radius / distance_squared, 0.0f)) - 1.0f);
+        const float radius = s->radius;
+        z = 1.0f + r2 * (__builtin_sqrtf(fmax_ref(1.0f - radius * radius / distance_squared, 0.0f)) - 1.0f);
         rad = __builtin_sqrtf(fmax_ref(1.0f - z * z, 0.0f));
     } else {  // random_cosine_direction
         z = __builtin_sqrtf(1.0f - r2);
@@ -809,7 +842,7 @@ RRT_DEV f3 sample_scatter_direction(const DScene& sc, f3 n, f3 from, Rng& g) {
     float sp, cp;
     det_sincos(phi, &sp, &cp);
     f3 d = onb_local(axis, mk3(cp * rad, sp * rad, z));
-    if (sphere_light) d = xform_vec(s->l2w, d);
+    if (sphere_light) d = xform_vec((cf1p)s->l2w, d);
     return d;
 }
 
@@ -833,8 +866,8 @@ RRT_DEV float schlick_ref(float cosine, float index) {
 template <uint32_t FEAT>
 RRT_DEV f3 albedo_value(const DScene& sc, int tex, float u, float v, f3 p) {
     if (FEAT & F_TEX) return texture_value(sc, tex, u, v, p);
-    const rrt_texture& t = sc.textures[tex];
-    return mk3(t.a, t.b, t.c);
+    const ctexture_p t = sc.c_textures() + tex;
+    return mk3(t->a, t->b, t->c);
 }
 RRT_DEV f3 bump_normal(const DScene& sc, const HitProps& hp, int bump_tex) {
     const float delta = 0.005f;
@@ -881,7 +914,8 @@ RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, ui
         hp.u = clampf(hp.u, 0.0f, 1.0f);  // aggregate.rs:31
         hp.v = clampf(hp.v, 0.0f, 1.0f);
     }
-    const rrt_material m = sc.materials[mat_id];
+    const cmaterial_p mp = sc.c_materials() + mat_id;
+    struct { uint32_t type; int32_t albedo, bump; float param; } m = {mp->type, mp->albedo, mp->bump, mp->param};
     if (m.type == RRT_MAT_DIFFUSE_LIGHT) {  // material.rs:229-231: emission ends the path
         *radiance = albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
         return true;

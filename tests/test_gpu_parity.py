@@ -136,6 +136,10 @@ def test_render_sample_ranges_and_tiles(gpu):
     assert np.array_equal(bits(tiled), bits(full))
 
 
+def test_fast_reciprocal_is_exact_for_every_float(gpu):
+    assert rrt.selftest_reciprocal() == 0
+
+
 def test_resolve_rgb8(gpu):
     rng = np.random.default_rng(0)
     img = rng.uniform(0, 40, (33, 47, 3)).astype(np.float32)
