@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librrt_hip.so")
+LIB_PATH = os.environ.get("RRT_LIB") or os.path.join(_HERE, "librrt_hip.so")
 
 BG_BLACK, BG_SKY = 0, 1
 AABB_TIGHT, AABB_REFERENCE = 0, 1

@@ -26,7 +26,10 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
-def build(force=False, verbose=False):
+def build(force=False, verbose=False, extra_flags=(), out=None):
+    global LIB
+    if out:
+        LIB = out
     if not force and not needs_build():
         return LIB
     objs = []
@@ -36,7 +39,7 @@ def build(force=False, verbose=False):
     for src in SOURCES:
         obj = os.path.join(bdir, src.replace("/", "_") + ".o")
         objs.append(obj)
-        cmd = [hipcc()] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc()] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd))
         procs.append((cmd, subprocess.Popen(cmd)))

@@ -37,8 +37,11 @@ struct TraceArgs {
 // Path state (ray, throughput, RNG) lives in registers for the whole path; the BVH short stack is in LDS.
 // Every sample's radiance goes to slab[sample][y][x] (12 bytes per path); k_accumulate then adds a pixel's samples in
 // sample order, which makes the image independent of how samples were scheduled.
+#ifndef RRT_TRACE_MIN_WAVES
+#define RRT_TRACE_MIN_WAVES 1  // waves per SIMD the register allocator must leave room for
+#endif
 template <int AABB_MODE, uint32_t FEAT>
-__global__ __launch_bounds__(kTraceBlock) void k_trace(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t lane = threadIdx.x;
     const uint32_t chunk = blockIdx.x / ta.n_t8, j = blockIdx.x % ta.n_t8;
@@ -348,7 +351,37 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         rc = upload(src, count, (const void**)&s->d.field, &s->owned);               \
         if (rc) { rrt_scene_destroy(s); return rc; }                                 \
     } while (0)
-    UP(nodes, (const float4*)desc->nodes, (size_t)desc->n_nodes * 2);
+    // Device copy of the tree: leaves reference pair records (two primitives interleaved component-wise, 96 bytes).
+    {
+        std::vector<rrt_node> dn(desc->nodes, desc->nodes + desc->n_nodes);
+        std::vector<float> pairs;
+        auto put_u = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+        for (rrt_node& n : dn) {
+            if (!(n.b & RRT_LEAF_FLAG)) continue;
+            const uint32_t first = n.a, count = n.b & ~RRT_LEAF_FLAG;
+            n.a = (uint32_t)(pairs.size() / 24);
+            for (uint32_t k = 0; k < count; k += 2) {
+                const rrt_slot& A = desc->slots[first + k];
+                const bool has_b = k + 1 < count;
+                const rrt_slot& B = desc->slots[first + (has_b ? k + 1 : k)];
+                const float* av[3] = {A.v0, A.e1, A.e2};
+                const float* bv[3] = {B.v0, B.e1, B.e2};
+                for (int v = 0; v < 3; ++v)
+                    for (int c = 0; c < 3; ++c) {
+                        pairs.push_back(av[v][c]);
+                        pairs.push_back(bv[v][c]);
+                    }
+                pairs.push_back(put_u(A.info));
+                pairs.push_back(put_u(has_b ? B.info : (RRT_KIND_NONE << 30)));
+                pairs.push_back(put_u(first + k));
+                pairs.push_back(put_u(first + (has_b ? k + 1 : k)));
+                pairs.push_back(put_u(A.prim));
+                pairs.push_back(put_u(B.prim));
+            }
+        }
+        UP(nodes, (const float4*)dn.data(), (size_t)dn.size() * 2);
+        UP(pairs, (const float4*)pairs.data(), pairs.size() / 4);
+    }
     UP(slots, (const float4*)desc->slots, (size_t)desc->n_slots * 3);
     UP(tri_shade, (const float4*)desc->tri_shade, (size_t)desc->n_slots * 4);
     UP(spheres, desc->spheres, desc->n_spheres);

@@ -202,7 +202,8 @@ RRT_DEV f3 xyz(v4f q) { return f3{q.x, q.y, q.z}; }
 
 // ---- device view of the scene ----------------------------------------------------------------------
 struct DScene {
-    const float4* nodes;      // 2 x float4 per rrt_node
+    const float4* nodes;      // 2 x float4 per rrt_node; a leaf's `a` holds its first PAIR index
+    const float4* pairs;      // 6 x float4 per two consecutive primitives of a leaf (see triangle_pair_hit)
     const float4* slots;      // 3 x float4 per rrt_slot
     const float4* tri_shade;  // 4 x float4 per rrt_tri_shade
     const rrt_sphere* spheres;
@@ -217,6 +218,7 @@ struct DScene {
     rrt_camera cam;
 
     RRT_DEV cv4p c_nodes() const { return (cv4p)(const void*)nodes; }
+    RRT_DEV cv4p c_pairs() const { return (cv4p)(const void*)pairs; }
     RRT_DEV cv4p c_slots() const { return (cv4p)(const void*)slots; }
     RRT_DEV cv4p c_tri_shade() const { return (cv4p)(const void*)tri_shade; }
     RRT_DEV cv4p c_btris() const { return (cv4p)(const void*)btris; }
@@ -575,35 +577,103 @@ struct Hit {
 
 // One primitive of a leaf against the ray: updates `h` when it is hit closer than h.t (strict, first visited wins ties).
 template <uint32_t FEAT>
-RRT_DEV void test_slot(const DScene& sc, f3 v0, uint32_t prim, f3 e1, uint32_t info, f3 e2, uint32_t aux, int s, const Ray& r, float t_min,
-                       const Rng& key, uint32_t depth, Hit& h) {
+RRT_DEV void test_slot(const DScene& sc, uint32_t s, const Ray& r, float t_min, const Rng& key, uint32_t depth, Hit& h) {
+    const cv4p cslots = sc.c_slots();
+    const v4f q0 = cslots[3 * s], q1 = cslots[3 * s + 1], q2 = cslots[3 * s + 2];
+    const uint32_t info = __float_as_uint(q1.w);
     const uint32_t kind = RRT_INFO_KIND(info);
     if (!(FEAT & (F_SPHERE | F_MEDIUM)) || kind == RRT_KIND_TRIANGLE) {
         float t, u, v, det;
-        if (triangle_hit_uv(v0, e1, e2, (info & RRT_INFO_CULL) != 0, r, t_min, h.t, &t, &u, &v, &det)) {
+        if (triangle_hit_uv(xyz(q0), xyz(q1), xyz(q2), (info & RRT_INFO_CULL) != 0, r, t_min, h.t, &t, &u, &v, &det)) {
             h.t = t;
-            h.slot = s;
+            h.slot = (int)s;
             h.u = u;
             h.v = v;
             h.det = det;
         }
     } else if ((FEAT & F_SPHERE) && kind == RRT_KIND_SPHERE) {
         float t;
-        if (sphere_hit(sc.c_spheres() + aux, r, t_min, h.t, &t)) {
+        if (sphere_hit(sc.c_spheres() + __float_as_uint(q2.w), r, t_min, h.t, &t)) {
             h.t = t;
-            h.slot = s;
+            h.slot = (int)s;
         }
     } else if (FEAT & F_MEDIUM) {
         float t;
-        float xi = rng_keyed(key, depth, prim);
-        if (medium_hit(sc, sc.c_media() + aux, r, t_min, h.t, xi, &t)) {
+        float xi = rng_keyed(key, depth, __float_as_uint(q0.w));
+        if (medium_hit(sc, sc.c_media() + __float_as_uint(q2.w), r, t_min, h.t, xi, &t)) {
             h.t = t;
-            h.slot = s;
+            h.slot = (int)s;
         }
     }
 }
 
+// Two consecutive triangles of a leaf at once.  The pair record interleaves the two triangles component by component
+// (v0x_A, v0x_B, v0y_A, v0y_B, ...), so every multiply / add / subtract of Triangle::hit (shape.rs:335-372) is one packed
+// two-lane f32 instruction; each lane of a packed operation rounds exactly like the scalar one, and the two results are
+// accepted in leaf order (A, then B against the distance A may have shortened), so the outcome equals two single tests.
+typedef float v2f __attribute__((ext_vector_type(2)));
+RRT_DEV v2f splat2(float x) { return v2f{x, x}; }
+RRT_DEV void triangle_pair_hit(v4f q0, v4f q1, v4f q2, v4f q3, v4f q4, v4f q5, const Ray& r, float t_min, Hit& h) {
+    const v2f v0x = q0.xy, v0y = q0.zw, v0z = q1.xy, e1x = q1.zw, e1y = q2.xy, e1z = q2.zw, e2x = q3.xy, e2y = q3.zw, e2z = q4.xy;
+    const uint32_t info_a = __float_as_uint(q4.z), info_b = __float_as_uint(q4.w);
+    const v2f dx = splat2(r.d.x), dy = splat2(r.d.y), dz = splat2(r.d.z);
+    // p_vec = dir x edge_2 ; determinant = edge_1 . p_vec
+    const v2f px = (dy * e2z) - (dz * e2y);
+    const v2f py = (dz * e2x) - (dx * e2z);
+    const v2f pz = (dx * e2y) - (dy * e2x);
+    const v2f det = ((e1x * px) + (e1y * py)) + (e1z * pz);
+    bool ok_a = (info_a & RRT_INFO_CULL) ? !(det.x < RRT_EPS) : !(det.x > -RRT_EPS && det.x < RRT_EPS);
+    bool ok_b = (info_b & RRT_INFO_CULL) ? !(det.y < RRT_EPS) : !(det.y > -RRT_EPS && det.y < RRT_EPS);
+    if (!(ok_a || ok_b)) return;
+    // a rejected triangle's determinant may be 0: keep it away from the reciprocal, its lane is ignored from here on
+    const v2f inv = v2f{exact_rcp(ok_a ? det.x : 1.0f), exact_rcp(ok_b ? det.y : 1.0f)};
+    const v2f tx = splat2(r.o.x) - v0x, ty = splat2(r.o.y) - v0y, tz = splat2(r.o.z) - v0z;
+    const v2f u = (((tx * px) + (ty * py)) + (tz * pz)) * inv;
+    ok_a = ok_a && !(u.x < 0.0f || u.x > 1.0f);
+    ok_b = ok_b && !(u.y < 0.0f || u.y > 1.0f);
+    if (!(ok_a || ok_b)) return;
+    // q_vec = t_vec x edge_1
+    const v2f qx = (ty * e1z) - (tz * e1y);
+    const v2f qy = (tz * e1x) - (tx * e1z);
+    const v2f qz = (tx * e1y) - (ty * e1x);
+    const v2f v = (((dx * qx) + (dy * qy)) + (dz * qz)) * inv;
+    const v2f uv = u + v;
+    ok_a = ok_a && !(v.x < 0.0f || uv.x > 1.0f);
+    ok_b = ok_b && !(v.y < 0.0f || uv.y > 1.0f);
+    if (!(ok_a || ok_b)) return;
+    const v2f t = (((e2x * qx) + (e2y * qy)) + (e2z * qz)) * inv;
+    if (ok_a && t.x < h.t && t.x > t_min) {
+        h.t = t.x;
+        h.slot = (int)__float_as_uint(q5.x);
+        h.u = u.x;
+        h.v = v.x;
+        h.det = det.x;
+    }
+    if (ok_b && t.y < h.t && t.y > t_min) {
+        h.t = t.y;
+        h.slot = (int)__float_as_uint(q5.y);
+        h.u = u.y;
+        h.v = v.y;
+        h.det = det.y;
+    }
+}
+
+#define RRT_KIND_NONE 3u  // second half of an odd leaf's last pair
+
+template <uint32_t FEAT>
+RRT_DEV void test_pair(const DScene& sc, cv4p rec, const Ray& r, float t_min, const Rng& key, uint32_t depth, Hit& h) {
+    const v4f q4 = rec[4], q5 = rec[5];
+    const uint32_t kind_a = RRT_INFO_KIND(__float_as_uint(q4.z)), kind_b = RRT_INFO_KIND(__float_as_uint(q4.w));
+    if (kind_a == RRT_KIND_TRIANGLE && kind_b == RRT_KIND_TRIANGLE) {
+        triangle_pair_hit(rec[0], rec[1], rec[2], rec[3], q4, q5, r, t_min, h);
+    } else {
+        test_slot<FEAT>(sc, __float_as_uint(q5.x), r, t_min, key, depth, h);
+        if (kind_b != RRT_KIND_NONE) test_slot<FEAT>(sc, __float_as_uint(q5.y), r, t_min, key, depth, h);
+    }
+}
+
 // `stack` points at this lane's first entry of an LDS array laid out [entry][thread]; `stride` = threads per block.
+// Leaves are stored as pair records (6 x float4 per two primitives); a leaf node's `a` is its first pair.
 template <int AABB_MODE, uint32_t FEAT>
 RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack, uint32_t stride) {
     Hit h;
@@ -612,7 +682,7 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
     h.u = h.v = h.det = 0.0f;
     if (sc.n_nodes == 0) return h;
     const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-    const cv4p cslots = sc.c_slots();
+    const cv4p cpairs = sc.c_pairs();
     const cv4p cnodes = sc.c_nodes();
     uint32_t sp = 0;
     uint32_t cur = 0;
@@ -630,30 +700,11 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
                     // Every lane that reached a leaf is in the SAME leaf (always so for the one- and few-leaf trees the
                     // reference builds for small scenes): walk it with wave-uniform indices, so primitive records come
                     // through the scalar cache into SGPRs and the kind dispatch is a scalar branch.
-                    const uint32_t count = ub & ~RRT_LEAF_FLAG;
-                    for (uint32_t k = 0; k < count; ++k) {
-                        const uint32_t s = ua + k;
-                        const v4f q0 = cslots[3 * s], q1 = cslots[3 * s + 1], q2 = cslots[3 * s + 2];
-                        const uint32_t info = __float_as_uint(q1.w);
-                        if ((FEAT & F_SPHERE) && RRT_INFO_KIND(info) == RRT_KIND_SPHERE) {
-                            float t;
-                            if (sphere_hit(sc.c_spheres() + __float_as_uint(q2.w), r, t_min, h.t, &t)) {
-                                h.t = t;
-                                h.slot = (int)s;
-                            }
-                        } else {
-                            test_slot<FEAT>(sc, mk3(q0.x, q0.y, q0.z), __float_as_uint(q0.w), mk3(q1.x, q1.y, q1.z), info, mk3(q2.x, q2.y, q2.z),
-                                            __float_as_uint(q2.w), (int)s, r, t_min, key, depth, h);
-                        }
-                    }
+                    const uint32_t n_pairs = ((ub & ~RRT_LEAF_FLAG) + 1u) >> 1;
+                    for (uint32_t k = 0; k < n_pairs; ++k) test_pair<FEAT>(sc, cpairs + 6 * (ua + k), r, t_min, key, depth, h);
                 } else {
-                    const uint32_t count = b & ~RRT_LEAF_FLAG;
-                    for (uint32_t k = 0; k < count; ++k) {
-                        const uint32_t s = a + k;
-                        const v4f q0 = cslots[3 * s], q1 = cslots[3 * s + 1], q2 = cslots[3 * s + 2];
-                        test_slot<FEAT>(sc, xyz(q0), __float_as_uint(q0.w), xyz(q1), __float_as_uint(q1.w), xyz(q2), __float_as_uint(q2.w), (int)s, r,
-                                        t_min, key, depth, h);
-                    }
+                    const uint32_t n_pairs = ((b & ~RRT_LEAF_FLAG) + 1u) >> 1;
+                    for (uint32_t k = 0; k < n_pairs; ++k) test_pair<FEAT>(sc, cpairs + 6 * (a + k), r, t_min, key, depth, h);
                 }
             } else {
                 // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
