@@ -9,9 +9,11 @@ rank renders its own 1024-sample range of the per-pixel random streams (first_sa
 radiance sums are combined with ONE RCCL reduce per step, so N GPUs deliver an N*1024-spp frame: weak scaling.
 `--shard tiles` instead splits one 1024-spp frame into interleaved 32x32 tiles (strong scaling).
 
-Rank 0 prints one JSON line.  `roofline` prices the render kernel with the per-ray byte figure of a
-queue-based wavefront tracer (192 B per path segment); this kernel keeps path state in registers, so its
-measured HBM traffic is far below that figure and the kernel is VALU-bound — see DESIGN.md.
+Rank 0 prints one JSON line.  `roofline` is for the dominant kernel, k_trace: its launch durations are measured
+live with HIP events that the library records around every launch on the render stream, and `achieved` prices the
+rays of one launch with the per-ray byte figure of a queue-based wavefront tracer (192 B per path segment).
+k_trace keeps path state in registers, so its measured HBM traffic (`traffic`, from the committed PMC passes) is the
+12 bytes per path it writes and the kernel is VALU-bound, not HBM-bound.
 `cpu_baseline` times the CPU oracle (a port of the reference's algorithm) on a bounded sample of the same
 frame on this host's cores; it is never part of the product path.
 """
@@ -88,6 +90,8 @@ def main():
     else:
         kw = dict(samples=args.spp, first_sample=0, seed=0, aabb_mode=aabb, tile_count=world, tile_index=rank)
 
+    scene.set_timing(True)
+
     def step(ev0=None, ev1=None):
         stream = torch.cuda.current_stream()
         if args.shard == "tiles":
@@ -108,6 +112,7 @@ def main():
         step()
     fence()
     counters.zero_()
+    scene.kernel_times()  # forget the warm-up passes
     torch.cuda.synchronize()
     events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     fence()
@@ -124,11 +129,13 @@ def main():
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
     elapsed = float(t.item())
     rays_total, paths_total = int(c[0].item()), int(c[1].item())
-    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    render_ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    trace_ms, accumulate_ms, passes = scene.kernel_times()
 
     if rank == 0:
-        rays_per_launch = int(counters[0].item()) / max(args.steps, 1)
-        k_s = float(np.mean(kernel_ms)) * 1e-3
+        launches = max(passes, 1)  # one k_trace launch per pass of the staging buffer
+        rays_per_launch = int(counters[0].item()) / launches
+        k_s = trace_ms / launches * 1e-3
         achieved = rays_per_launch * BYTES_PER_RAY / k_s / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -136,7 +143,7 @@ def main():
             with open(pmc) as f:
                 rec = json.load(f)
             if rec.get("spp") == args.spp and rec.get("width") == WIDTH:
-                traffic = rec.get("hbm_bytes_per_launch")
+                traffic = rec.get("hbm_bytes_per_launch")  # PMC passes of the same command, corrected for gfx950
         out = {
             "metric": "Mrays/sec (whole node) + time-to-image, Cornell box 1024^2 @1024 spp",
             "value": rays_total / elapsed / 1e6,
@@ -156,8 +163,9 @@ def main():
                        "samples_per_second": paths_total / elapsed, "rays_per_path": rays_total / max(paths_total, 1),
                        "time_to_image_ms": elapsed / max(args.steps, 1) * 1e3},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_render", "kernel_ms": float(np.mean(kernel_ms)),
-                         "bytes_per_ray": BYTES_PER_RAY, "rays_per_launch": rays_per_launch},
+                         "traffic": traffic, "kernel": "k_trace", "kernel_ms": k_s * 1e3, "launches_per_step": launches / max(args.steps, 1),
+                         "bytes_per_ray": BYTES_PER_RAY, "rays_per_launch": rays_per_launch,
+                         "accumulate_ms_per_step": accumulate_ms / max(args.steps, 1), "render_ms_per_step": float(np.mean(render_ms))},
         }
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_spp)

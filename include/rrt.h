@@ -251,6 +251,13 @@ int rrt_render(rrt_scene*, const rrt_render_params* params, float* rgb_sum, rrt_
  * d_counters: optional device buffer of 2 uint64 {rays, paths} that the kernel adds to. */
 int rrt_render_device(rrt_scene*, const rrt_render_params* params, float* d_rgb_sum, uint64_t* d_counters, void* stream);
 
+/* Per-kernel timing (≙ the reference's only instrumentation, the wall clock of main.rs:64, 191, split by kernel).
+ * While enabled, every render pass records device events around its trace and accumulate kernels on the caller's
+ * stream; rrt_scene_kernel_times waits for the recorded passes, returns the summed durations in milliseconds and the
+ * number of passes, and forgets them. */
+int rrt_scene_set_timing(rrt_scene*, int enable);
+int rrt_scene_kernel_times(rrt_scene*, double* trace_ms, double* accumulate_ms, uint32_t* passes);
+
 /* ≙ main.rs:173-186: out[i] = (u8)(sqrt(sum[i] / spp) * 255.99), saturating, NaN -> 0.  Host buffers. */
 int rrt_resolve_rgb8(const float* rgb_sum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* out);
 int rrt_resolve_rgb8_device(const float* d_rgb_sum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_out, void* stream);

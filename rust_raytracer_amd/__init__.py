@@ -127,6 +127,8 @@ def lib():
     L.rrt_intersect_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rrt_render.argtypes = [vp, C.POINTER(_RenderParams), vp, C.POINTER(_Stats)]
     L.rrt_render_device.argtypes = [vp, C.POINTER(_RenderParams), vp, vp, vp]
+    L.rrt_scene_set_timing.argtypes = [vp, C.c_int]
+    L.rrt_scene_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.rrt_resolve_rgb8.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
     L.rrt_resolve_rgb8_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.rrt_probe.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp]
@@ -319,6 +321,16 @@ class Scene:
                          kw.get("background", BG_BLACK), kw.get("max_depth", -1), kw.get("aabb_mode", AABB_TIGHT), kw.get("tile_count", 1),
                          kw.get("tile_index", 0))
         _check(lib().rrt_render_device(self._h, C.byref(p), d_rgb_sum, d_counters or None, stream or None))
+
+    def set_timing(self, enable=True):
+        """Record device events around the trace and accumulate kernels of every following render pass."""
+        _check(lib().rrt_scene_set_timing(self._h, 1 if enable else 0))
+
+    def kernel_times(self):
+        """(trace_ms, accumulate_ms, passes) summed over the passes recorded since the last call; waits for them."""
+        t, a, n = C.c_double(0), C.c_double(0), C.c_uint32(0)
+        _check(lib().rrt_scene_kernel_times(self._h, C.byref(t), C.byref(a), C.byref(n)))
+        return t.value, a.value, n.value
 
     def probe(self, which, arg, inp, out_words):
         inp = np.ascontiguousarray(inp)

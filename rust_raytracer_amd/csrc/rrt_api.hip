@@ -255,6 +255,10 @@ struct rrt_scene {
     uint32_t features = 0;  // F_* bits the scene needs
     uint32_t n_spheres = 0, n_media = 0, n_btris = 0, n_materials = 0, n_textures = 0;
     int device = 0;
+    // optional per-kernel timing: three events per pass (before k_trace, between the kernels, after k_accumulate)
+    bool timing = false;
+    std::vector<hipEvent_t> events;  // pool
+    size_t events_used = 0;          // multiples of three
 };
 
 static int validate_desc(const rrt_scene_desc* d) {
@@ -421,10 +425,35 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     return RRT_OK;
 }
 
+int rrt_scene_set_timing(rrt_scene* s, int enable) {
+    if (!s) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_set_timing: NULL scene");
+    s->timing = enable != 0;
+    return RRT_OK;
+}
+
+int rrt_scene_kernel_times(rrt_scene* s, double* trace_ms, double* accumulate_ms, uint32_t* passes) {
+    if (!s) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_kernel_times: NULL scene");
+    double t = 0.0, a = 0.0;
+    for (size_t i = 0; i + 3 <= s->events_used; i += 3) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventSynchronize(s->events[i + 2]));
+        HIP_TRY(hipEventElapsedTime(&ms, s->events[i], s->events[i + 1]));
+        t += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, s->events[i + 1], s->events[i + 2]));
+        a += ms;
+    }
+    if (trace_ms) *trace_ms = t;
+    if (accumulate_ms) *accumulate_ms = a;
+    if (passes) *passes = (uint32_t)(s->events_used / 3);
+    s->events_used = 0;
+    return RRT_OK;
+}
+
 void rrt_scene_destroy(rrt_scene* s) {
     if (!s) return;
     for (void* p : s->owned) (void)hipFree(p);
     if (s->slab) (void)hipFree(s->slab);
+    for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
     delete s;
 }
 
@@ -535,6 +564,17 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
     const uint32_t need = s->features;
     unsigned long long* cnt = (unsigned long long*)d_counters;
     for (uint32_t done = 0; done < plan.spp; done += (uint32_t)per_pass) {
+        hipEvent_t* ev = nullptr;
+        if (s->timing) {
+            while (s->events.size() < s->events_used + 3) {
+                hipEvent_t e;
+                HIP_TRY(hipEventCreate(&e));
+                s->events.push_back(e);
+            }
+            ev = &s->events[s->events_used];
+            s->events_used += 3;
+            HIP_TRY(hipEventRecord(ev[0], st));
+        }
         ta.n_samples = plan.spp - done < per_pass ? plan.spp - done : (uint32_t)per_pass;
         ta.first_sample = plan.ta.first_sample + done;
         const uint64_t items = (uint64_t)((ta.n_samples + kChunk - 1) / kChunk) * ta.n_t8;
@@ -552,9 +592,11 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         }
 #undef RRT_LAUNCH
         HIP_TRY(hipGetLastError());
+        if (ev) HIP_TRY(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((frame_floats + 255) / 256)), dim3(256), 0, st, s->slab, ta.n_samples, frame_floats, ta.W,
                            ta.tiles_x, ta.tile_count, ta.tile_index, done == 0 ? 1 : 0, d_rgb_sum);
         HIP_TRY(hipGetLastError());
+        if (ev) HIP_TRY(hipEventRecord(ev[2], st));
     }
     return RRT_OK;
 }
