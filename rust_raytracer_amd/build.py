@@ -27,17 +27,15 @@ def needs_build():
 
 
 def build(force=False, verbose=False, extra_flags=(), out=None):
-    global LIB
-    if out:
-        LIB = out
-    if not force and not needs_build():
-        return LIB
+    lib = out or LIB
+    if not out and not force and not needs_build():
+        return lib
     objs = []
     bdir = os.path.join(HERE, "build")
     os.makedirs(bdir, exist_ok=True)
     procs = []
     for src in SOURCES:
-        obj = os.path.join(bdir, src.replace("/", "_") + ".o")
+        obj = os.path.join(bdir, (os.path.basename(out) + "." if out else "") + src.replace("/", "_") + ".o")
         objs.append(obj)
         cmd = [hipcc()] + FLAGS + list(extra_flags) + ["-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
@@ -46,11 +44,11 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     for cmd, p in procs:
         if p.wait() != 0:
             raise RuntimeError("compile failed: " + " ".join(cmd))
-    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-o", LIB] + objs + ["-lz"]
+    cmd = [hipcc(), "--offload-arch=gfx950", "-shared", "-o", lib] + objs + ["-lz"]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
-    return LIB
+    return lib
 
 
 if __name__ == "__main__":

@@ -38,7 +38,7 @@ struct TraceArgs {
 // Every sample's radiance goes to slab[sample][y][x] (12 bytes per path); k_accumulate then adds a pixel's samples in
 // sample order, which makes the image independent of how samples were scheduled.
 #ifndef RRT_TRACE_MIN_WAVES
-#define RRT_TRACE_MIN_WAVES 1  // waves per SIMD the register allocator must leave room for
+#define RRT_TRACE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
 template <int AABB_MODE, uint32_t FEAT>
 __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
@@ -65,7 +65,18 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
     Rng g;
     r.o = r.d = thr = mk3(0.0f, 0.0f, 0.0f);
     g.s0 = g.s1 = 0;
+#ifdef RRT_PHASE_PROFILE
+    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#define RRT_TICK(i) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tick_; tick_ = now_; }
+    unsigned long long tick_ = __builtin_readcyclecounter();
+#else
+#define RRT_TICK(i)
+#endif
     while (alive) {
+#ifdef RRT_PHASE_PROFILE
+        pc[4] += 1;
+        pc[5] += __popcll(__ballot(fresh));
+#endif
         if (fresh) {
             px = x0 + (idx & 7u);
             py = y0 + ((idx >> 3) & 7u);
@@ -80,12 +91,19 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
             }
             fresh = false;
         }
+        RRT_TICK(0)
         bool done = true;
         if (valid) {
             Hit hit = closest_hit<AABB_MODE, FEAT>(sc, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock);
+            RRT_TICK(1)
             ++rays;
             f3 radiance;
             done = shade<FEAT>(sc, hit, r, thr, g, depth, ta.max_depth, ta.bg, &radiance);
+            RRT_TICK(2)
+#ifdef RRT_PHASE_PROFILE
+            pc[6] += __popcll(__ballot(true));
+            pc[7] += __popcll(__ballot(done));
+#endif
             if (done) {
                 f3 c = thr * radiance;
                 float* q = slab + (((size_t)smp * ta.H + py) * ta.W + px) * 3;
@@ -104,7 +122,12 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
             fresh = true;
         }
         next += (uint32_t)__popcll(finished);
+        RRT_TICK(3)
     }
+#ifdef RRT_PHASE_PROFILE
+    if (counters && lane == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&counters[2 + i], pc[i]);
+#endif
     if (counters) {
         for (int off = 32; off > 0; off >>= 1) {
             rays += __shfl_down(rays, off);

@@ -394,17 +394,25 @@ RRT_DEV float texture_bump_value(const DScene& sc, int tex, float u, float v, f3
 }
 
 // ---- exact reciprocal ------------------------------------------------------------------------------------------
-// 1.0f / x, correctly rounded, in 3 instructions for 2^-100 <= |x| <= 2^100: the hardware reciprocal estimate plus one
-// fused Newton step.  Equality with IEEE division was checked on gfx950 for every float in that range
-// (rrt_selftest_reciprocal repeats the exhaustive check); outside it the full division sequence runs.
-RRT_DEV float rcp_newton(float x) {
-    float r0 = __builtin_amdgcn_rcpf(x);
-    float e = __builtin_fmaf(-x, r0, 1.0f);
-    return __builtin_fmaf(e, r0, r0);
-}
+// 1.0f / x, correctly rounded: the hardware reciprocal estimate plus one fused Newton step, accepted when the step's
+// residual e = 1 - x*r0 is small.  On gfx950 that is exact for every float whose residual passes (all normal x whose
+// reciprocal is normal; zero, denormal, huge and non-finite x fail the residual test and take the full division);
+// rrt_selftest_reciprocal repeats the exhaustive comparison with IEEE division over all 2^32 bit patterns.
+#define RRT_RCP_RESIDUAL 9.5367431640625e-07f  // 2^-20
 RRT_DEV float exact_rcp(float x) {
-    if (__builtin_fabsf(x) >= 7.888609052210118e-31f && __builtin_fabsf(x) <= 1.2676506002282294e30f) return rcp_newton(x);
+#ifdef RRT_RCP_RANGE
+    if (__builtin_fabsf(x) >= 7.888609052210118e-31f && __builtin_fabsf(x) <= 1.2676506002282294e30f) {
+        const float r0 = __builtin_amdgcn_rcpf(x);
+        const float e = __builtin_fmaf(-x, r0, 1.0f);
+        return __builtin_fmaf(e, r0, r0);
+    }
     return 1.0f / x;
+#else
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r0, 1.0f);
+    if (__builtin_fabsf(e) <= RRT_RCP_RESIDUAL) return __builtin_fmaf(e, r0, r0);
+    return 1.0f / x;
+#endif
 }
 
 // ---- primitives ----------------------------------------------------------------------------------------------
@@ -622,34 +630,53 @@ RRT_DEV void triangle_pair_hit(v4f q0, v4f q1, v4f q2, v4f q3, v4f q4, v4f q5, c
     const v2f py = (dz * e2x) - (dx * e2z);
     const v2f pz = (dx * e2y) - (dy * e2x);
     const v2f det = ((e1x * px) + (e1y * py)) + (e1z * pz);
-    bool ok_a = (info_a & RRT_INFO_CULL) ? !(det.x < RRT_EPS) : !(det.x > -RRT_EPS && det.x < RRT_EPS);
-    bool ok_b = (info_b & RRT_INFO_CULL) ? !(det.y < RRT_EPS) : !(det.y > -RRT_EPS && det.y < RRT_EPS);
+    // the cull flags are wave-uniform; the common all-culled pair takes a scalar branch to the plain comparisons
+    bool ok_a, ok_b;
+    if (info_a & info_b & RRT_INFO_CULL) {
+        asm volatile("");  // keeps the two arms apart (merged, they cost a per-lane select each)
+        ok_a = !(det.x < RRT_EPS);
+        ok_b = !(det.y < RRT_EPS);
+    } else {
+        ok_a = (info_a & RRT_INFO_CULL) ? !(det.x < RRT_EPS) : !(__builtin_fabsf(det.x) < RRT_EPS);
+        ok_b = (info_b & RRT_INFO_CULL) ? !(det.y < RRT_EPS) : !(__builtin_fabsf(det.y) < RRT_EPS);
+    }
     if (!(ok_a || ok_b)) return;
-    // a rejected triangle's determinant may be 0: keep it away from the reciprocal, its lane is ignored from here on
-    const v2f inv = v2f{exact_rcp(ok_a ? det.x : 1.0f), exact_rcp(ok_b ? det.y : 1.0f)};
+    // 1 / determinant for both triangles: reciprocal estimate + one fused Newton step (see exact_rcp); when the residual of
+    // either is not small (zero, denormal, huge or non-finite determinant) the whole wave takes the division instead
+    const v2f r0 = v2f{__builtin_amdgcn_rcpf(det.x), __builtin_amdgcn_rcpf(det.y)};
+    const v2f e = __builtin_elementwise_fma(-det, r0, splat2(1.0f));
+    v2f inv = __builtin_elementwise_fma(e, r0, r0);
+    if (__builtin_expect(__ballot(!(__builtin_fabsf(e.x) <= RRT_RCP_RESIDUAL) || !(__builtin_fabsf(e.y) <= RRT_RCP_RESIDUAL)) != 0ull, 0))
+        inv = v2f{1.0f / det.x, 1.0f / det.y};
     const v2f tx = splat2(r.o.x) - v0x, ty = splat2(r.o.y) - v0y, tz = splat2(r.o.z) - v0z;
     const v2f u = (((tx * px) + (ty * py)) + (tz * pz)) * inv;
-    ok_a = ok_a && !(u.x < 0.0f || u.x > 1.0f);
-    ok_b = ok_b && !(u.y < 0.0f || u.y > 1.0f);
-    if (!(ok_a || ok_b)) return;
     // q_vec = t_vec x edge_1
     const v2f qx = (ty * e1z) - (tz * e1y);
     const v2f qy = (tz * e1x) - (tx * e1z);
     const v2f qz = (tx * e1y) - (ty * e1x);
     const v2f v = (((dx * qx) + (dy * qy)) + (dz * qz)) * inv;
     const v2f uv = u + v;
-    ok_a = ok_a && !(v.x < 0.0f || uv.x > 1.0f);
-    ok_b = ok_b && !(v.y < 0.0f || uv.y > 1.0f);
-    if (!(ok_a || ok_b)) return;
     const v2f t = (((e2x * qx) + (e2y * qy)) + (e2z * qz)) * inv;
-    if (ok_a && t.x < h.t && t.x > t_min) {
+    // acceptance in the reference's order of tests; the comparisons are written so that NaNs fall the same way
+    ok_a = ok_a & !(u.x < 0.0f) & !(u.x > 1.0f) & !(v.x < 0.0f) & !(uv.x > 1.0f) & (t.x > t_min);
+    ok_b = ok_b & !(u.y < 0.0f) & !(u.y > 1.0f) & !(v.y < 0.0f) & !(uv.y > 1.0f) & (t.y > t_min);
+    // A first, then B against the distance A may have shortened (leaf order)
+    const bool take_a = ok_a && t.x < h.t;
+    const bool take_b = ok_b && t.y < (take_a ? t.x : h.t);
+    if (take_a) {
+#ifdef RRT_FORCE_BRANCH
+        asm volatile("");
+#endif
         h.t = t.x;
         h.slot = (int)__float_as_uint(q5.x);
         h.u = u.x;
         h.v = v.x;
         h.det = det.x;
     }
-    if (ok_b && t.y < h.t && t.y > t_min) {
+    if (take_b) {
+#ifdef RRT_FORCE_BRANCH
+        asm volatile("");
+#endif
         h.t = t.y;
         h.slot = (int)__float_as_uint(q5.y);
         h.u = u.y;
