@@ -195,7 +195,13 @@ typedef struct rrt_render_params {
     uint32_t aabb_mode;       /* RRT_AABB_* */
     uint32_t tile_count;      /* interleaved 32x32-pixel tile sharding: this call renders tiles with index % tile_count == tile_index; 0/1 = all */
     uint32_t tile_index;
+    uint32_t flags;           /* RRT_RENDER_* */
 } rrt_render_params;
+
+/* rrt_render_params.flags.  ACCUMULATE: the output buffer already holds the sums of the samples before first_sample and
+ * this call's samples are added after them, in sample order (main.rs:244-245), so rendering [0,a) then [a,b) with the flag
+ * gives bit for bit what one call over [0,b) gives; without it the call's pixels start from zero. */
+enum { RRT_RENDER_ACCUMULATE = 1 };
 
 typedef struct rrt_stats {
     uint64_t rays;          /* Aggregate::hit calls made by trace (aggregate.rs:24) */
@@ -261,6 +267,10 @@ int rrt_scene_kernel_times(rrt_scene*, double* trace_ms, double* accumulate_ms, 
 /* ≙ main.rs:173-186: out[i] = (u8)(sqrt(sum[i] / spp) * 255.99), saturating, NaN -> 0.  Host buffers. */
 int rrt_resolve_rgb8(const float* rgb_sum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* out);
 int rrt_resolve_rgb8_device(const float* d_rgb_sum, uint32_t width, uint32_t height, uint32_t spp, uint8_t* d_out, void* stream);
+
+/* ≙ PNGEncoder::encode(&data, res_x, res_y, ColorType::RGB(8)) on a file opened with create_new (main.rs:98-107, 188):
+ * writes an 8-bit RGB PNG; with create_new != 0 an existing file is an RRT_ERR_IO error ("Failed to create new file"). */
+int rrt_write_png(const char* path, const uint8_t* rgb, uint32_t width, uint32_t height, int create_new);
 
 /* Device-side unit probes used by the parity tests (each ≙ the named reference function, evaluated on the GPU):
  *   which = 0 camera rays for (px,py,sample) triples in `in` (3 u32 each) -> 6 floats            (main.rs:227-229, camera.rs:53-63)

@@ -16,6 +16,7 @@ LIB_PATH = os.environ.get("RRT_LIB") or os.path.join(_HERE, "librrt_hip.so")
 
 BG_BLACK, BG_SKY = 0, 1
 AABB_TIGHT, AABB_REFERENCE = 0, 1
+RENDER_ACCUMULATE = 1
 KIND_TRIANGLE, KIND_SPHERE, KIND_MEDIUM = 0, 1, 2
 T_MIN = 0.001
 T_MAX = float(np.finfo(np.float32).max)
@@ -82,7 +83,7 @@ class _SceneDesc(C.Structure):
 class _RenderParams(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("samples", C.c_uint32), ("first_sample", C.c_uint32), ("seed", C.c_uint32),
                 ("background", C.c_uint32), ("max_depth", C.c_int32), ("aabb_mode", C.c_uint32), ("tile_count", C.c_uint32),
-                ("tile_index", C.c_uint32)]
+                ("tile_index", C.c_uint32), ("flags", C.c_uint32)]
 
 
 class _Stats(C.Structure):
@@ -133,6 +134,7 @@ def lib():
     L.rrt_resolve_rgb8_device.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp, vp]
     L.rrt_probe.argtypes = [vp, C.c_uint32, C.c_uint32, vp, C.c_size_t, vp]
     L.rrt_selftest_reciprocal.argtypes = [C.POINTER(C.c_uint64)]
+    L.rrt_write_png.argtypes = [C.c_char_p, vp, C.c_uint32, C.c_uint32, C.c_int]
     _lib = L
     return L
 
@@ -299,18 +301,19 @@ class Scene:
                                          t.ctypes.data))
         return prim, t
 
-    def _params(self, width, height, samples, first_sample, seed, background, max_depth, aabb_mode, tile_count, tile_index):
+    def _params(self, width, height, samples, first_sample, seed, background, max_depth, aabb_mode, tile_count, tile_index, accumulate=False):
         return _RenderParams(width or 0, height or 0, samples or 0, first_sample, seed, background, max_depth, aabb_mode, tile_count,
-                             tile_index)
+                             tile_index, RENDER_ACCUMULATE if accumulate else 0)
 
     def render(self, width=None, height=None, samples=None, first_sample=0, seed=0, background=BG_BLACK, max_depth=-1,
-               aabb_mode=AABB_TIGHT, tile_count=1, tile_index=0, out=None):
-        """Per-pixel radiance sums, float32 [H, W, 3], and the stats dict (rays, paths, seconds)."""
+               aabb_mode=AABB_TIGHT, tile_count=1, tile_index=0, out=None, accumulate=False):
+        """Per-pixel radiance sums, float32 [H, W, 3], and the stats dict (rays, paths, seconds).
+        With accumulate=True the samples are added to the sums already in `out` (earlier sample ranges)."""
         W, H = width or self.width, height or self.height
         img = out if out is not None else np.zeros((H, W, 3), dtype=np.float32)
         if img.shape != (H, W, 3) or img.dtype != np.float32 or not img.flags["C_CONTIGUOUS"]:
             raise ValueError("out must be a C-contiguous float32 array of shape (H, W, 3)")
-        p = self._params(width, height, samples, first_sample, seed, background, max_depth, aabb_mode, tile_count, tile_index)
+        p = self._params(width, height, samples, first_sample, seed, background, max_depth, aabb_mode, tile_count, tile_index, accumulate)
         st = _Stats()
         _check(lib().rrt_render(self._h, C.byref(p), img.ctypes.data, C.byref(st)))
         return img, {"rays": st.rays, "paths": st.paths, "seconds": st.render_seconds}
@@ -319,7 +322,7 @@ class Scene:
         """Enqueues the render on `stream` into a device buffer (raw pointers as ints); does not synchronise."""
         p = self._params(kw.get("width"), kw.get("height"), kw.get("samples"), kw.get("first_sample", 0), kw.get("seed", 0),
                          kw.get("background", BG_BLACK), kw.get("max_depth", -1), kw.get("aabb_mode", AABB_TIGHT), kw.get("tile_count", 1),
-                         kw.get("tile_index", 0))
+                         kw.get("tile_index", 0), kw.get("accumulate", False))
         _check(lib().rrt_render_device(self._h, C.byref(p), d_rgb_sum, d_counters or None, stream or None))
 
     def set_timing(self, enable=True):
@@ -349,6 +352,14 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+def write_png(path, rgb8, create_new=True):
+    """Writes an (H, W, 3) uint8 image as PNG; refuses to overwrite an existing file unless create_new is False."""
+    a = np.ascontiguousarray(rgb8, dtype=np.uint8)
+    if a.ndim != 3 or a.shape[2] != 3:
+        raise ValueError("rgb8 must have shape (H, W, 3)")
+    _check(lib().rrt_write_png(os.fsencode(path), a.ctypes.data, a.shape[1], a.shape[0], 1 if create_new else 0))
 
 
 def selftest_reciprocal():

@@ -7,9 +7,10 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librrt_hip.so")
+CLI = os.path.join(HERE, "rust-raytracer")
 
 SOURCES = ["rrt_api.hip", "rrt_error.cpp", "host/scene_host.cpp", "host/scene_json.cpp", "host/image_io.cpp", "host/image_codecs.cpp"]
-HEADERS = ["rrt_device.hpp", "rrt_error.hpp", "host/scene_host.hpp", "host/hmath.hpp", "../../include/rrt.h"]
+HEADERS = ["cli/main.cpp", "rrt_device.hpp", "rrt_error.hpp", "host/scene_host.hpp", "host/hmath.hpp", "../../include/rrt.h"]
 
 # -ffp-contract=off: the reference never fuses a*b+c; bit-exact hit decisions need unfused f32 on host and device.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
@@ -20,7 +21,7 @@ def hipcc():
 
 
 def needs_build():
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(CLI):
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
@@ -48,7 +49,19 @@ def build(force=False, verbose=False, extra_flags=(), out=None):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    if not out:
+        build_cli(verbose)
     return lib
+
+
+def build_cli(verbose=False):
+    """The command line front end: plain C++ on top of the C ABI, finds librrt_hip.so next to itself."""
+    cmd = [shutil.which("g++") or "g++", "-O2", "-std=c++17", "-Wall", "-I", os.path.join(HERE, "..", "include"),
+           os.path.join(CSRC, "cli", "main.cpp"), "-o", CLI, "-L", HERE, "-l:librrt_hip.so", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return CLI
 
 
 if __name__ == "__main__":

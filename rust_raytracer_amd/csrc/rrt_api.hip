@@ -534,6 +534,7 @@ static int plan_render(rrt_scene* s, const rrt_render_params* p, RenderPlan* pla
     if (!s || !p) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: NULL argument");
     if (p->aabb_mode > RRT_AABB_REFERENCE) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: unknown aabb_mode");
     if (p->background > RRT_BG_SKY) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: unknown background");
+    if (p->flags & ~(uint32_t)RRT_RENDER_ACCUMULATE) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: unknown flags");
     TraceArgs& ta = plan->ta;
     ta.W = p->width ? p->width : s->res_x;
     ta.H = p->height ? p->height : s->res_y;
@@ -569,6 +570,10 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
     if (per_pass == 0) per_pass = 1;
     if (per_pass > plan.spp) per_pass = plan.spp;
     if (per_pass >= kChunk) per_pass -= per_pass % kChunk;
+    // equal passes (in whole chunks) rather than full ones plus a short tail: every pass then fills the chip for as long
+    const uint64_t n_passes = (plan.spp + per_pass - 1) / per_pass;
+    const uint64_t even = ((plan.spp + n_passes - 1) / n_passes + kChunk - 1) / kChunk * kChunk;
+    if (even < per_pass) per_pass = even;
     const size_t need_bytes = (size_t)per_pass * frame_bytes;
     if (s->slab_bytes < need_bytes) {
         if (s->slab) {
@@ -617,7 +622,7 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((frame_floats + 255) / 256)), dim3(256), 0, st, s->slab, ta.n_samples, frame_floats, ta.W,
-                           ta.tiles_x, ta.tile_count, ta.tile_index, done == 0 ? 1 : 0, d_rgb_sum);
+                           ta.tiles_x, ta.tile_count, ta.tile_index, (done == 0 && !(p->flags & RRT_RENDER_ACCUMULATE)) ? 1 : 0, d_rgb_sum);
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev[2], st));
     }
