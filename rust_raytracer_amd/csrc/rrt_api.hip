@@ -1,7 +1,9 @@
 // Kernels and the device half of the C ABI (include/rrt.h).
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstring>
+#include <limits>
 #include <string>
 #include <vector>
 
@@ -367,6 +369,80 @@ static int validate_desc(const rrt_scene_desc* d) {
 
 extern "C" {
 
+// The reference's node boxes all contain the world origin (every union in new_bvh_helper starts from the point box at
+// the origin, aggregate.rs:195, 423-428), so they overlap heavily and cull little.  This computes, bottom-up, the boxes
+// the primitives actually occupy, padded by 1e-5 of the scene's largest coordinate.  The TIGHT traversal accepts a node
+// only if the reference's test accepts the reference's box AND the ray overlaps this box: a node rejected by the second
+// condition holds nothing the ray can hit, so the closest hit (and every later decision, which depends only on the
+// closest distance so far) is the reference's.  Two float4 per node: (lo, 0), (hi, 0).
+static std::vector<float> tight_boxes(const rrt_scene_desc* d) {
+    const uint32_t n = d->n_nodes;
+    std::vector<float> tb((size_t)n * 8, 0.0f);
+    float scene_max = 0.0f;
+    for (uint32_t i = 0; i < n; ++i)
+        for (int c = 0; c < 3; ++c) scene_max = std::fmax(scene_max, std::fmax(std::fabs(d->nodes[i].bmin[c]), std::fabs(d->nodes[i].bmax[c])));
+    const float pad = 1.0e-5f * scene_max + 1.0e-30f;
+    auto grow = [](float* b, const float* p) {
+        for (int c = 0; c < 3; ++c) {
+            b[c] = std::fmin(b[c], p[c]);
+            b[4 + c] = std::fmax(b[4 + c], p[c]);
+        }
+    };
+    auto grow_sphere = [&](float* b, const rrt_sphere& sp) {
+        // corners of the local cube [-|r|, |r|]^3 through local_to_world: their box contains the transformed sphere
+        const float r = std::fabs(sp.radius);
+        for (int k = 0; k < 8; ++k) {
+            const float x = (k & 1) ? r : -r, y = (k & 2) ? r : -r, z = (k & 4) ? r : -r;
+            float p[3];
+            for (int c = 0; c < 3; ++c) p[c] = sp.l2w[4 * c] * x + sp.l2w[4 * c + 1] * y + sp.l2w[4 * c + 2] * z + sp.l2w[4 * c + 3];
+            grow(b, p);
+        }
+    };
+    auto grow_triangle = [&](float* b, const rrt_slot& t) {
+        float v1[3], v2[3];
+        for (int c = 0; c < 3; ++c) {
+            v1[c] = t.v0[c] + t.e1[c];
+            v2[c] = t.v0[c] + t.e2[c];
+        }
+        grow(b, t.v0);
+        grow(b, v1);
+        grow(b, v2);
+    };
+    for (uint32_t i = n; i-- > 0;) {  // pre-order layout: children follow their parent
+        const rrt_node& nd = d->nodes[i];
+        float* b = &tb[(size_t)i * 8];
+        const float inf = std::numeric_limits<float>::infinity();
+        b[0] = b[1] = b[2] = inf;
+        b[4] = b[5] = b[6] = -inf;
+        if (nd.b & RRT_LEAF_FLAG) {
+            const uint32_t first = nd.a, count = nd.b & ~RRT_LEAF_FLAG;
+            for (uint32_t k = 0; k < count; ++k) {
+                const rrt_slot& sl = d->slots[first + k];
+                const uint32_t kind = RRT_INFO_KIND(sl.info);
+                if (kind == RRT_KIND_TRIANGLE) grow_triangle(b, sl);
+                else if (kind == RRT_KIND_SPHERE) grow_sphere(b, d->spheres[sl.aux]);
+                else {
+                    const rrt_medium& m = d->media[sl.aux];
+                    if (m.boundary_kind == RRT_KIND_SPHERE) grow_sphere(b, d->spheres[m.boundary_index]);
+                    else grow_triangle(b, d->boundary_tris[m.boundary_index]);
+                }
+            }
+            for (int c = 0; c < 3; ++c) {
+                b[c] -= pad;
+                b[4 + c] += pad;
+            }
+        } else {
+            const float* l = &tb[(size_t)(i + 1) * 8];
+            const float* r = &tb[(size_t)nd.a * 8];
+            for (int c = 0; c < 3; ++c) {
+                b[c] = std::fmin(l[c], r[c]);
+                b[4 + c] = std::fmax(l[4 + c], r[4 + c]);
+            }
+        }
+    }
+    return tb;
+}
+
 int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     if (!desc || !out) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_create: NULL argument");
     int rc = validate_desc(desc);
@@ -408,6 +484,8 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         }
         UP(nodes, (const float4*)dn.data(), (size_t)dn.size() * 2);
         UP(pairs, (const float4*)pairs.data(), pairs.size() / 4);
+        std::vector<float> tb = tight_boxes(desc);
+        UP(tboxes, (const float4*)tb.data(), tb.size() / 4);
     }
     UP(slots, (const float4*)desc->slots, (size_t)desc->n_slots * 3);
     UP(tri_shade, (const float4*)desc->tri_shade, (size_t)desc->n_slots * 4);
@@ -696,6 +774,17 @@ int rrt_resolve_rgb8(const float* rgb_sum, uint32_t W, uint32_t H, uint32_t spp,
     cleanup();
     return RRT_OK;
 }
+
+#ifdef RRT_PHASE_PROFILE
+// profiling build only: reads and clears the traversal counters
+extern "C" int rrt_profile_read(uint64_t* out8) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_prof), 64));
+    uint64_t zero[8] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, 64));
+    return RRT_OK;
+}
+#endif
 
 int rrt_selftest_reciprocal(uint64_t* mismatches) {
     if (!mismatches) return rrt_set_error(RRT_ERR_INVALID, "rrt_selftest_reciprocal: NULL argument");

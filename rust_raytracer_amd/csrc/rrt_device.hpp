@@ -204,6 +204,7 @@ RRT_DEV f3 xyz(v4f q) { return f3{q.x, q.y, q.z}; }
 struct DScene {
     const float4* nodes;      // 2 x float4 per rrt_node; a leaf's `a` holds its first PAIR index
     const float4* pairs;      // 6 x float4 per two consecutive primitives of a leaf (see triangle_pair_hit)
+    const float4* tboxes;     // 2 x float4 per node: the padded box its primitives occupy (TIGHT traversal)
     const float4* slots;      // 3 x float4 per rrt_slot
     const float4* tri_shade;  // 4 x float4 per rrt_tri_shade
     const rrt_sphere* spheres;
@@ -219,6 +220,7 @@ struct DScene {
 
     RRT_DEV cv4p c_nodes() const { return (cv4p)(const void*)nodes; }
     RRT_DEV cv4p c_pairs() const { return (cv4p)(const void*)pairs; }
+    RRT_DEV cv4p c_tboxes() const { return (cv4p)(const void*)tboxes; }
     RRT_DEV cv4p c_slots() const { return (cv4p)(const void*)slots; }
     RRT_DEV cv4p c_tri_shade() const { return (cv4p)(const void*)tri_shade; }
     RRT_DEV cv4p c_btris() const { return (cv4p)(const void*)btris; }
@@ -533,14 +535,11 @@ RRT_DEV void slab(float lo, float hi, float o, float inv, float* t0, float* t1) 
     *t0 = neg ? b : a;
     *t1 = neg ? a : b;
 }
-// AABB::intersect (aggregate.rs:471-503).  REFERENCE mode is the reference's test verbatim: an exit is honoured
-// only against the running ENTRY bound (`t1 < t_min`), so many boxes the ray misses are still accepted.
-// TIGHT mode accepts a box only if the reference's test accepts it AND the slab intervals really overlap
-// (smallest exit >= largest entry, with a 1e-5 relative margin so that rounding never culls a box whose
-// primitive can be hit).  TIGHT therefore visits a subset of the reference's boxes and, for primitives that
-// lie inside their boxes, reports the same closest hit.
-template <int AABB_MODE>
-RRT_DEV bool aabb_test(f3 bmin, f3 bmax, f3 o, f3 inv, float t_min, float t_max) {
+// AABB::intersect (aggregate.rs:471-503), the reference's test verbatim: an exit is honoured only against the running
+// ENTRY bound (`t1 < t_min`), so many boxes the ray misses are still accepted — and a few it hits are rejected, which the
+// reference's images depend on.  Both traversal modes apply it to the reference's boxes; TIGHT additionally requires
+// box_overlap() with the node's primitive box (see closest_hit).
+RRT_DEV bool aabb_reference(f3 bmin, f3 bmax, f3 o, f3 inv, float t_min, float t_max) {
     float t0x, t1x, t0y, t1y, t0z, t1z;
     slab(bmin.x, bmax.x, o.x, inv.x, &t0x, &t1x);
     slab(bmin.y, bmax.y, o.y, inv.y, &t0y, &t1y);
@@ -553,15 +552,18 @@ RRT_DEV bool aabb_test(f3 bmin, f3 bmax, f3 o, f3 inv, float t_min, float t_max)
     if (hi2 <= lo2) return false;
     float lo3 = t0z > lo2 ? t0z : lo2;
     float hi3 = t1z < lo2 ? t1z : hi2;
-    if (hi3 <= lo3) return false;
-    if (AABB_MODE == RRT_AABB_REFERENCE) return true;
-    float ex = t_max;
-    ex = t1x < ex ? t1x : ex;
-    ex = t1y < ex ? t1y : ex;
-    ex = t1z < ex ? t1z : ex;
-    float ex_pad = ex + __builtin_fabsf(ex) * 1.0e-5f;
-    float lo_pad = lo3 - __builtin_fabsf(lo3) * 1.0e-5f;
-    return ex_pad >= lo_pad;
+    return !(hi3 <= lo3);
+}
+
+// Does the ray's (t_min, t_max) span overlap the box?  The ordinary three-slab interval test; min/max drop NaNs (0 * inf
+// for a ray lying in a face plane), so such an axis constrains nothing and the test errs towards accepting.
+RRT_DEV bool box_overlap(f3 lo, f3 hi, f3 o, f3 inv, float t_min, float t_max) {
+    const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+    const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+    const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+    const float t_near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), t_min));
+    const float t_far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
+    return t_near <= t_far;
 }
 
 // ---- scene features a kernel variant is compiled for ------------------------------------------------------------------
@@ -575,6 +577,11 @@ enum : uint32_t {
     F_ALL = 15u
 };
 
+
+#ifdef RRT_PHASE_PROFILE
+// profiling build only: per-lane node visits, per-lane pair tests, wave-level node steps, wave-level pair steps
+__device__ unsigned long long g_prof[8];
+#endif
 
 // ---- closest hit: BVH::hit (aggregate.rs:324-401) with List::hit (aggregate.rs:144-165) in the leaves ------------
 struct Hit {
@@ -711,14 +718,28 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
     const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     const cv4p cpairs = sc.c_pairs();
     const cv4p cnodes = sc.c_nodes();
+    const cv4p ctboxes = sc.c_tboxes();
     uint32_t sp = 0;
     uint32_t cur = 0;
+#ifdef RRT_PHASE_PROFILE
+    unsigned long long prof_nodes = 0, prof_pairs = 0, prof_steps = 0, prof_leaf_steps = 0;
+#define RRT_COUNT(x, n) x += (n)
+#else
+#define RRT_COUNT(x, n)
+#endif
     for (;;) {
+        RRT_COUNT(prof_nodes, 1);
+#ifdef RRT_PHASE_PROFILE
+        if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_steps;  // first active lane
+#endif
         const v4f n0 = cnodes[2 * cur];
         const v4f n1 = cnodes[2 * cur + 1];
         bool inside;
         if (sc.is_list) inside = true;
-        else inside = aabb_test<AABB_MODE>(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
+        else if (AABB_MODE == RRT_AABB_TIGHT) {
+            const v4f b0 = ctboxes[2 * cur], b1 = ctboxes[2 * cur + 1];
+            inside = box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
+        } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
         if (inside) {
             const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
             if (b & RRT_LEAF_FLAG) {
@@ -731,7 +752,13 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
                     for (uint32_t k = 0; k < n_pairs; ++k) test_pair<FEAT>(sc, cpairs + 6 * (ua + k), r, t_min, key, depth, h);
                 } else {
                     const uint32_t n_pairs = ((b & ~RRT_LEAF_FLAG) + 1u) >> 1;
-                    for (uint32_t k = 0; k < n_pairs; ++k) test_pair<FEAT>(sc, cpairs + 6 * (a + k), r, t_min, key, depth, h);
+                    RRT_COUNT(prof_pairs, n_pairs);
+                    for (uint32_t k = 0; k < n_pairs; ++k) {
+#ifdef RRT_PHASE_PROFILE
+                        if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_leaf_steps;
+#endif
+                        test_pair<FEAT>(sc, cpairs + 6 * (a + k), r, t_min, key, depth, h);
+                    }
                 }
             } else {
                 // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
@@ -748,6 +775,12 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
         --sp;
         cur = stack[sp * stride];
     }
+#ifdef RRT_PHASE_PROFILE
+    atomicAdd(&g_prof[0], prof_nodes);
+    atomicAdd(&g_prof[1], prof_pairs);
+    atomicAdd(&g_prof[2], prof_steps);
+    atomicAdd(&g_prof[3], prof_leaf_steps);
+#endif
     return h;
 }
 

@@ -10,6 +10,7 @@ import pytest
 import orc
 import rays as raygen
 import rust_raytracer_amd as rrt
+import synth
 
 pytestmark = pytest.mark.gpu
 
@@ -134,6 +135,28 @@ def test_render_sample_ranges_and_tiles(gpu):
     for k in range(3):
         g.render(seed=3, tile_count=3, tile_index=k, out=tiled)
     assert np.array_equal(bits(tiled), bits(full))
+
+
+@pytest.mark.parametrize("cull", [False, True])
+def test_mesh_with_a_deep_tree_bit_exact(gpu, cull):
+    """A 20 000-triangle displaced grid (7 000-node tree, leaves of up to 54 triangles, lanes in different leaves):
+    closest hits in both traversal modes and a small render against the oracle's reference-mode traversal."""
+    d = synth.terrain_desc(100, seed=2, width=40, height=40, samples=2, cull=cull)
+    o = orc.OracleScene(d)
+    g = rrt.Scene(synth.host_scene(d))
+    ro, rd = raygen.ray_batch(o, 40, 40, n_random=6000, seed=9)
+    p_ref, t_ref = o.intersect(ro, rd)
+    assert (p_ref >= 0).sum() > 2000
+    for mode in (rrt.AABB_TIGHT, rrt.AABB_REFERENCE):
+        p, t = g.hit(ro, rd, aabb_mode=mode)
+        assert np.array_equal(p, p_ref), "primitive ids differ in mode %d: %d rays" % (mode, (p != p_ref).sum())
+        assert np.array_equal(bits(t), bits(t_ref))
+    ref, st_ref = o.render(40, 40, 2, seed=1)
+    for mode in (rrt.AABB_TIGHT, rrt.AABB_REFERENCE):
+        img, st = g.render(seed=1, aabb_mode=mode)
+        same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), "%d of %d values differ (mode %d)" % ((~same).sum(), same.size, mode)
+        assert st["rays"] == int(st_ref[0])
 
 
 def test_fast_reciprocal_is_exact_for_every_float(gpu):
