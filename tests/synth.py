@@ -41,6 +41,37 @@ def terrain_desc(n, seed=1, width=64, height=64, samples=2, amplitude=0.15, cull
     }
 
 
+def spheres_desc(n=40, seed=3, width=48, height=40, samples=4):
+    """Rotated, anisotropically scaled spheres (whose reference bounding box, centre +- radius, ignores the scale and so does
+    not contain them), a few with negative radius, over a two-triangle floor; Lambert, Metal, Dielectric and one light."""
+    rng = np.random.default_rng(seed)
+    shapes = []
+    for i in range(n):
+        tr = [float(v) for v in rng.uniform(-4, 4, 3)]
+        tr[1] = float(rng.uniform(0.2, 3.0))
+        ro = [float(v) for v in rng.uniform(0, 360, 3)]
+        sc = [float(v) for v in rng.uniform(0.5, 3.0, 3)] if i % 3 else [1.0, 1.0, 1.0]
+        radius = float(rng.uniform(0.15, 0.5)) * (-1.0 if i % 11 == 5 else 1.0)
+        shapes.append({"type": "sphere", "radius": radius, "material": int(i % 4), "transform": (tr, ro, sc)})
+    floor_v = np.array([[-8, 0, -8], [8, 0, -8], [8, 0, 8], [-8, 0, 8]], dtype=np.float64)
+    floor_t = np.array([[0, 2, 1], [0, 3, 2]], dtype=np.int32)
+    shapes.append({"type": "mesh", "object": {"vertices": floor_v, "tex": np.zeros((0, 2)), "vidx": floor_t, "tidx": np.full_like(floor_t, -1)},
+                   "cull": False, "material": 0, "transform": ([0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])})
+    return {
+        "logistics": {"resolution_x": width, "resolution_y": height, "samples": samples, "use_importance_sampling": True},
+        "camera": {"position": [0.0, 3.0, 9.0], "look_at": [0.0, 1.0, 0.0], "up": [0.0, 1.0, 0.0], "fov": 50.0,
+                   "aspect_ratio": width / height, "aperture": 0.1, "focus_distance": 9.0},
+        "textures": [{"type": sceneio.TEX_CONSTANT, "color": [0.7, 0.6, 0.5]}, {"type": sceneio.TEX_CONSTANT, "color": [0.9, 0.9, 0.8]},
+                     {"type": sceneio.TEX_CONSTANT, "color": [6.0, 5.0, 4.0]}],
+        "materials": [{"type": sceneio.MAT_LAMBERT, "albedo": 0, "bump": -1, "param": 0.0},
+                      {"type": sceneio.MAT_METAL, "albedo": 1, "bump": -1, "param": 0.2},
+                      {"type": sceneio.MAT_DIELECTRIC, "albedo": -1, "bump": -1, "param": 1.5},
+                      {"type": sceneio.MAT_DIFFUSE_LIGHT, "albedo": 2, "bump": -1, "param": 0.0}],
+        "shapes": shapes,
+        "aggregate": 1,
+    }
+
+
 def host_scene(desc):
     """The product's host-side scene for a neutral description (constant textures, meshes and spheres)."""
     import rust_raytracer_amd as rrt

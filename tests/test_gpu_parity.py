@@ -159,6 +159,28 @@ def test_mesh_with_a_deep_tree_bit_exact(gpu, cull):
         assert st["rays"] == int(st_ref[0])
 
 
+def test_scaled_spheres_outside_their_reference_boxes_bit_exact(gpu):
+    """Sphere::get_bounding_box (shape.rs:129-139) ignores the scale, so scaled spheres stick out of their boxes and the
+    reference misses part of them; both traversal modes must reproduce exactly those hits and misses."""
+    d = synth.spheres_desc()
+    o = orc.OracleScene(d)
+    g = rrt.Scene(synth.host_scene(d))
+    ro, rd = raygen.ray_batch(o, 48, 40, n_random=8000, seed=4)
+    p_ref, t_ref = o.intersect(ro, rd)
+    p_list, _ = orc.OracleScene(dict(d, aggregate=0)).intersect(ro, rd)
+    assert (p_ref != p_list).sum() > 10, "the scene should make the BVH lose hits a plain list finds"
+    for mode in (rrt.AABB_TIGHT, rrt.AABB_REFERENCE):
+        p, t = g.hit(ro, rd, aabb_mode=mode)
+        assert np.array_equal(p, p_ref), "primitive ids differ in mode %d: %d rays" % (mode, (p != p_ref).sum())
+        assert np.array_equal(bits(t), bits(t_ref))
+    ref, st_ref = o.render(48, 40, 4, seed=2, bg=rrt.BG_SKY)
+    for mode in (rrt.AABB_TIGHT, rrt.AABB_REFERENCE):
+        img, st = g.render(seed=2, background=rrt.BG_SKY, aabb_mode=mode)
+        same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), "%d of %d values differ (mode %d)" % ((~same).sum(), same.size, mode)
+        assert st["rays"] == int(st_ref[0])
+
+
 def test_fast_reciprocal_is_exact_for_every_float(gpu):
     assert rrt.selftest_reciprocal() == 0
 
