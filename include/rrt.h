@@ -257,6 +257,11 @@ int rrt_render(rrt_scene*, const rrt_render_params* params, float* rgb_sum, rrt_
  * d_counters: optional device buffer of 2 uint64 {rays, paths} that the kernel adds to. */
 int rrt_render_device(rrt_scene*, const rrt_render_params* params, float* d_rgb_sum, uint64_t* d_counters, void* stream);
 
+/* Memory budget of the scene handle's per-sample radiance staging buffer (12 bytes per pixel per sample of a pass;
+ * default 4 GiB, 0 restores the default).  A frame whose samples do not fit is traced in several passes; the image
+ * does not depend on the split.  No counterpart in the reference (its colours vector, main.rs:115-121, is per pixel). */
+int rrt_scene_set_staging_limit(rrt_scene*, uint64_t bytes);
+
 /* Per-kernel timing (≙ the reference's only instrumentation, the wall clock of main.rs:64, 191, split by kernel).
  * While enabled, every render pass records device events around its trace and accumulate kernels on the caller's
  * stream; rrt_scene_kernel_times waits for the recorded passes, returns the summed durations in milliseconds and the

@@ -128,6 +128,7 @@ def lib():
     L.rrt_intersect_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rrt_render.argtypes = [vp, C.POINTER(_RenderParams), vp, C.POINTER(_Stats)]
     L.rrt_render_device.argtypes = [vp, C.POINTER(_RenderParams), vp, vp, vp]
+    L.rrt_scene_set_staging_limit.argtypes = [vp, C.c_uint64]
     L.rrt_scene_set_timing.argtypes = [vp, C.c_int]
     L.rrt_scene_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.rrt_resolve_rgb8.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
@@ -324,6 +325,10 @@ class Scene:
                          kw.get("background", BG_BLACK), kw.get("max_depth", -1), kw.get("aabb_mode", AABB_TIGHT), kw.get("tile_count", 1),
                          kw.get("tile_index", 0), kw.get("accumulate", False))
         _check(lib().rrt_render_device(self._h, C.byref(p), d_rgb_sum, d_counters or None, stream or None))
+
+    def set_staging_limit(self, nbytes):
+        """Memory budget of the per-sample radiance staging buffer (0 = the 4 GiB default)."""
+        _check(lib().rrt_scene_set_staging_limit(self._h, nbytes))
 
     def set_timing(self, enable=True):
         """Record device events around the trace and accumulate kernels of every following render pass."""

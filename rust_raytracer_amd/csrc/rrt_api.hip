@@ -276,6 +276,7 @@ struct rrt_scene {
     std::vector<void*> owned;
     float* slab = nullptr;  // per-sample radiance staging, allocated on first render
     size_t slab_bytes = 0;
+    size_t slab_cap = kSlabCapBytes;
     uint32_t res_x = 0, res_y = 0, samples = 0, stack_depth = 1;
     uint32_t features = 0;  // F_* bits the scene needs
     uint32_t n_spheres = 0, n_media = 0, n_btris = 0, n_materials = 0, n_textures = 0;
@@ -526,6 +527,12 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     return RRT_OK;
 }
 
+int rrt_scene_set_staging_limit(rrt_scene* s, uint64_t bytes) {
+    if (!s) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_set_staging_limit: NULL scene");
+    s->slab_cap = bytes ? (size_t)bytes : kSlabCapBytes;
+    return RRT_OK;
+}
+
 int rrt_scene_set_timing(rrt_scene* s, int enable) {
     if (!s) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_set_timing: NULL scene");
     s->timing = enable != 0;
@@ -644,7 +651,7 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
     const size_t frame_floats = (size_t)ta.W * ta.H * 3;
     const size_t frame_bytes = frame_floats * sizeof(float);
     // samples per pass: as many as fit the staging buffer, in whole chunks when possible
-    uint64_t per_pass = kSlabCapBytes / frame_bytes;
+    uint64_t per_pass = s->slab_cap / frame_bytes;
     if (per_pass == 0) per_pass = 1;
     if (per_pass > plan.spp) per_pass = plan.spp;
     if (per_pass >= kChunk) per_pass -= per_pass % kChunk;

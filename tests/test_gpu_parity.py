@@ -181,6 +181,22 @@ def test_scaled_spheres_outside_their_reference_boxes_bit_exact(gpu):
         assert st["rays"] == int(st_ref[0])
 
 
+def test_render_is_independent_of_the_pass_split_and_of_odd_sizes(gpu):
+    """Frames that are no multiple of the 8x8 wave tile, sample counts that are no multiple of the 64-sample chunk, and
+    staging budgets that force 1, 5 and 70 passes all give the oracle's bits."""
+    W, H, spp = 45, 19, 70
+    o, g = both("Cornell_Box_With_Sphere.json", resolution_x=W, resolution_y=H, samples=spp)
+    ref, st_ref = o.render(W, H, spp, seed=8)
+    for limit in (0, W * H * 12 * 16, W * H * 12):
+        g.set_staging_limit(limit)
+        img, st = g.render(seed=8)
+        assert np.array_equal(bits(img), bits(ref)), "staging limit %d" % limit
+        assert st["rays"] == int(st_ref[0]) and st["paths"] == W * H * spp
+    g.set_staging_limit(0)
+    one, _ = g.render(width=1, height=1, samples=3, seed=8)
+    assert one.shape == (1, 1, 3) and np.isfinite(one).all()
+
+
 def test_fast_reciprocal_is_exact_for_every_float(gpu):
     assert rrt.selftest_reciprocal() == 0
 
