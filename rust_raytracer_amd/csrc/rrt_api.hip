@@ -565,10 +565,21 @@ void rrt_scene_destroy(rrt_scene* s) {
     delete s;
 }
 
+// A scene's buffers live on the device that was current in rrt_scene_create; launching from another device would hand
+// the kernels pointers that device cannot reach.
+static int check_device(const rrt_scene* s) {
+    int cur = -1;
+    HIP_TRY(hipGetDevice(&cur));
+    if (cur != s->device)
+        return rrt_set_error(RRT_ERR_INVALID, "the scene was created on device " + std::to_string(s->device) + " but the current device is " + std::to_string(cur));
+    return RRT_OK;
+}
+
 int rrt_intersect_batch_device(rrt_scene* s, const float* d_o, const float* d_d, size_t n, float t_min, float t_max, uint32_t aabb_mode,
                                uint32_t seed, int32_t* d_prim, float* d_t, void* stream) {
     if (!s || (n && (!d_o || !d_d || !d_prim || !d_t))) return rrt_set_error(RRT_ERR_INVALID, "rrt_intersect_batch: NULL argument");
     if (aabb_mode > RRT_AABB_REFERENCE) return rrt_set_error(RRT_ERR_INVALID, "rrt_intersect_batch: unknown aabb_mode");
+    if (int rc = check_device(s)) return rc;
     if (n == 0) return RRT_OK;
     if (n > (size_t)0x7fffffff * kBlock) return rrt_set_error(RRT_ERR_LIMIT, "rrt_intersect_batch: too many rays for one launch");
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
@@ -617,6 +628,7 @@ struct RenderPlan {
 
 static int plan_render(rrt_scene* s, const rrt_render_params* p, RenderPlan* plan) {
     if (!s || !p) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: NULL argument");
+    if (int rc = check_device(s)) return rc;
     if (p->aabb_mode > RRT_AABB_REFERENCE) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: unknown aabb_mode");
     if (p->background > RRT_BG_SKY) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: unknown background");
     if (p->flags & ~(uint32_t)RRT_RENDER_ACCUMULATE) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: unknown flags");
@@ -812,6 +824,7 @@ int rrt_probe(rrt_scene* s, uint32_t which, uint32_t arg, const void* in, size_t
     static const size_t in_words[5] = {3, 8, 5, 2, 2};
     static const size_t out_words[5] = {6, 14, 3, 5, 8};
     if (which > 4) return rrt_set_error(RRT_ERR_INVALID, "rrt_probe: unknown probe");
+    if (int rc = check_device(s)) return rc;
     if (which == 2 && arg >= s->n_textures) return rrt_set_error(RRT_ERR_INVALID, "rrt_probe: texture index out of range");
     if (n == 0) return RRT_OK;
     uint32_t* d_in = nullptr;
