@@ -82,6 +82,7 @@ def main():
 
     scene = rrt.Scene.load(SCENE, width=WIDTH, height=HEIGHT, samples=args.spp)  # upload happens here, outside the timed region
     img = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev)
+    rgb8 = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev)
     counters = torch.zeros(2, dtype=torch.int64, device=dev)
     aabb = rrt.AABB_TIGHT if args.aabb == "tight" else rrt.AABB_REFERENCE
     if args.shard == "samples":
@@ -102,6 +103,9 @@ def main():
         if ev1 is not None:
             ev1.record(stream)
         shard.reduce_frame(img, dst=0)  # the one collective of the job (no-op on one GPU)
+        if rank == 0:  # time-to-image ends with the 8-bit frame (main.rs:173-186), still in HBM
+            total_spp = args.spp * world if args.shard == "samples" else args.spp
+            rrt.resolve_rgb8_device(img.data_ptr(), WIDTH, HEIGHT, total_spp, rgb8.data_ptr(), torch.cuda.current_stream().cuda_stream)
 
     def fence():
         if world > 1:

@@ -18,6 +18,7 @@ constexpr int kBlock = 256;              // k_intersect: 4 waves per block
 constexpr int kTraceBlock = 64;          // k_trace: one wave per block, the unit the hardware dispatcher balances
 constexpr uint32_t kChunk = 64;          // samples of each pixel handled by one wave item
 constexpr uint32_t kMaxStackDepth = 64;  // LDS short stack: entries per lane
+constexpr uint32_t kDeepTreeNodes = 16;  // trees with more nodes than this take the cooperative-leaf walk
 constexpr size_t kSlabCapBytes = 4ull << 30;  // per-sample radiance staging buffer (per scene handle, per GPU)
 
 struct TraceArgs {
@@ -27,6 +28,7 @@ struct TraceArgs {
     uint32_t seed, bg, max_depth;
     uint32_t tile_count, tile_index, tiles_x, n_tiles;  // 32x32-pixel tiles (multi-GPU sharding unit)
     uint32_t n_t8;                                       // 8x8-pixel wave tiles owned by this call
+    uint32_t stack_depth;                                // LDS stack entries per lane (the cooperative-leaf area follows the stack)
 };
 
 // ---- the trace kernel -------------------------------------------------------------------------------------
@@ -42,7 +44,7 @@ struct TraceArgs {
 #ifndef RRT_TRACE_MIN_WAVES
 #define RRT_TRACE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
-template <int AABB_MODE, uint32_t FEAT>
+template <int AABB_MODE, uint32_t FEAT, bool DEEP>
 __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t lane = threadIdx.x;
@@ -74,12 +76,14 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
 #else
 #define RRT_TICK(i)
 #endif
-    while (alive) {
+    // DEEP: the closest-hit query is a whole-wave operation, so the loop runs until every lane's pool share is done and
+    // lanes without a path keep taking part (valid = false).
+    while (DEEP ? __ballot(alive) != 0ull : alive) {
 #ifdef RRT_PHASE_PROFILE
         pc[4] += 1;
         pc[5] += __popcll(__ballot(fresh));
 #endif
-        if (fresh) {
+        if (fresh && alive) {
             px = x0 + (idx & 7u);
             py = y0 + ((idx >> 3) & 7u);
             smp = s0 + (idx >> 6);
@@ -95,25 +99,29 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
         }
         RRT_TICK(0)
         bool done = true;
-        if (valid) {
-            Hit hit = closest_hit<AABB_MODE, FEAT>(sc, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock);
+        if (DEEP || valid) {
+            Hit hit;
+            if (DEEP) hit = closest_hit_deep<AABB_MODE, FEAT>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth));
+            else hit = closest_hit<AABB_MODE, FEAT>(sc, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock);
             RRT_TICK(1)
-            ++rays;
-            f3 radiance;
-            done = shade<FEAT>(sc, hit, r, thr, g, depth, ta.max_depth, ta.bg, &radiance);
-            RRT_TICK(2)
+            if (valid) {
+                ++rays;
+                f3 radiance;
+                done = shade<FEAT>(sc, hit, r, thr, g, depth, ta.max_depth, ta.bg, &radiance);
+                RRT_TICK(2)
 #ifdef RRT_PHASE_PROFILE
-            pc[6] += __popcll(__ballot(true));
-            pc[7] += __popcll(__ballot(done));
+                pc[6] += __popcll(__ballot(true));
+                pc[7] += __popcll(__ballot(done));
 #endif
-            if (done) {
-                f3 c = thr * radiance;
-                float* q = slab + (((size_t)smp * ta.H + py) * ta.W + px) * 3;
-                q[0] = c.x;
-                q[1] = c.y;
-                q[2] = c.z;
-            } else {
-                ++depth;
+                if (done) {
+                    f3 c = thr * radiance;
+                    float* q = slab + (((size_t)smp * ta.H + py) * ta.W + px) * 3;
+                    q[0] = c.x;
+                    q[1] = c.y;
+                    q[2] = c.z;
+                } else {
+                    ++depth;
+                }
             }
         }
         const unsigned long long finished = __ballot(done);
@@ -122,6 +130,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
             idx = next + rank;
             alive = idx < pool;
             fresh = true;
+            if (!alive) valid = false;
         }
         next += (uint32_t)__popcll(finished);
         RRT_TICK(3)
@@ -159,17 +168,28 @@ __global__ void k_accumulate(const float* __restrict__ slab, uint32_t n_samples,
 }
 
 // ≙ Aggregate::hit (aggregate.rs:118-124) for a batch of rays, one lane per ray.
-template <int AABB_MODE>
+template <int AABB_MODE, bool DEEP>
 __global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, const float* __restrict__ o, const float* __restrict__ d, size_t n, float t_min,
-                                                      float t_max, uint32_t seed, int* __restrict__ prim, float* __restrict__ t_hit) {
+                                                      float t_max, uint32_t seed, uint32_t stack_depth, int* __restrict__ prim, float* __restrict__ t_hit) {
     extern __shared__ uint32_t lds_stack[];
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
+    const bool active = i < n;
+    if (!DEEP && !active) return;
     Ray r;
-    r.o = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
-    r.d = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    r.o = r.d = mk3(0.0f, 0.0f, 1.0f);
+    if (active) {
+        r.o = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+        r.d = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+    }
     Rng g = rng_seed(seed, (uint32_t)i, 0);
-    Hit h = closest_hit<AABB_MODE, F_ALL>(sc, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock);
+    Hit h;
+    if (DEEP) {
+        unsigned char* coop = (unsigned char*)(lds_stack + kBlock * stack_depth) + (threadIdx.x >> 6) * kCoopBytesPerWave;
+        h = closest_hit_deep<AABB_MODE, F_ALL>(sc, active, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock, coop);
+    } else {
+        h = closest_hit<AABB_MODE, F_ALL>(sc, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock);
+    }
+    if (!active) return;
     prim[i] = h.slot >= 0 ? (int)__float_as_uint(sc.slots[3 * h.slot].w) : -1;
     t_hit[i] = h.t;
 }
@@ -279,6 +299,7 @@ struct rrt_scene {
     size_t slab_cap = kSlabCapBytes;
     uint32_t res_x = 0, res_y = 0, samples = 0, stack_depth = 1;
     uint32_t features = 0;  // F_* bits the scene needs
+    bool deep = false;      // many-node tree: kernels use the cooperative-leaf walk (closest_hit_deep)
     uint32_t n_spheres = 0, n_media = 0, n_btris = 0, n_materials = 0, n_textures = 0;
     int device = 0;
     // optional per-kernel timing: three events per pass (before k_trace, between the kernels, after k_accumulate)
@@ -483,10 +504,14 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                 pairs.push_back(put_u(B.prim));
             }
         }
-        UP(nodes, (const float4*)dn.data(), (size_t)dn.size() * 2);
+        const std::vector<float> tb = tight_boxes(desc);
+        std::vector<float> rec((size_t)dn.size() * 16);  // node (32 bytes) + primitive box (32 bytes) per 64-byte record
+        for (size_t i = 0; i < dn.size(); ++i) {
+            std::memcpy(&rec[i * 16], &dn[i], 32);
+            std::memcpy(&rec[i * 16 + 8], &tb[i * 8], 32);
+        }
+        UP(nodes, (const float4*)rec.data(), rec.size() / 4);
         UP(pairs, (const float4*)pairs.data(), pairs.size() / 4);
-        std::vector<float> tb = tight_boxes(desc);
-        UP(tboxes, (const float4*)tb.data(), tb.size() / 4);
     }
     UP(slots, (const float4*)desc->slots, (size_t)desc->n_slots * 3);
     UP(tri_shade, (const float4*)desc->tri_shade, (size_t)desc->n_slots * 4);
@@ -509,6 +534,7 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     s->samples = desc->samples;
     s->stack_depth = desc->bvh_depth ? desc->bvh_depth : 1;
     s->n_textures = desc->n_textures;
+    s->deep = desc->n_nodes > kDeepTreeNodes;
     // which code the scene needs (see F_* in rrt_device.hpp)
     for (uint32_t i = 0; i < desc->n_slots; ++i) {
         uint32_t kind = RRT_INFO_KIND(desc->slots[i].info);
@@ -583,12 +609,14 @@ int rrt_intersect_batch_device(rrt_scene* s, const float* d_o, const float* d_d,
     if (n == 0) return RRT_OK;
     if (n > (size_t)0x7fffffff * kBlock) return rrt_set_error(RRT_ERR_LIMIT, "rrt_intersect_batch: too many rays for one launch");
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-    size_t lds = (size_t)kBlock * s->stack_depth * sizeof(uint32_t);
+    size_t lds = (size_t)kBlock * s->stack_depth * sizeof(uint32_t) + (s->deep ? (size_t)(kBlock / 64) * kCoopBytesPerWave : 0);
     hipStream_t st = (hipStream_t)stream;
     if (aabb_mode == RRT_AABB_REFERENCE)
-        hipLaunchKernelGGL(k_intersect<RRT_AABB_REFERENCE>, grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, d_prim, d_t);
+        if (s->deep) hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
+        else hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE, false>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
     else
-        hipLaunchKernelGGL(k_intersect<RRT_AABB_TIGHT>, grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, d_prim, d_t);
+        if (s->deep) hipLaunchKernelGGL((k_intersect<RRT_AABB_TIGHT, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
+        else hipLaunchKernelGGL((k_intersect<RRT_AABB_TIGHT, false>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
     HIP_TRY(hipGetLastError());
     return RRT_OK;
 }
@@ -682,7 +710,8 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         HIP_TRY(hipMalloc((void**)&s->slab, need_bytes));
         s->slab_bytes = need_bytes;
     }
-    const size_t lds = (size_t)kTraceBlock * s->stack_depth * sizeof(uint32_t);
+    const size_t lds = (size_t)kTraceBlock * s->stack_depth * sizeof(uint32_t) + (s->deep ? kCoopBytesPerWave : 0);
+    ta.stack_depth = s->stack_depth;
     hipStream_t st = (hipStream_t)stream;
     // compiled variants: plain (triangles + spheres, constant textures), textured (+ textures, bump maps), full (+ media)
     constexpr uint32_t kPlain = F_SPHERE, kTextured = F_SPHERE | F_TEX | F_BUMP;
@@ -705,16 +734,19 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         const uint64_t items = (uint64_t)((ta.n_samples + kChunk - 1) / kChunk) * ta.n_t8;
         if (items > 0x7fffffffull) return rrt_set_error(RRT_ERR_LIMIT, "rrt_render: too many work items in one pass");
         const dim3 grid((unsigned)items);
-#define RRT_LAUNCH(MODE, FEAT) hipLaunchKernelGGL((k_trace<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt)
-        if (p->aabb_mode == RRT_AABB_REFERENCE) {
-            if ((need & ~kPlain) == 0) RRT_LAUNCH(RRT_AABB_REFERENCE, kPlain);
-            else if ((need & ~kTextured) == 0) RRT_LAUNCH(RRT_AABB_REFERENCE, kTextured);
-            else RRT_LAUNCH(RRT_AABB_REFERENCE, F_ALL);
-        } else {
-            if ((need & ~kPlain) == 0) RRT_LAUNCH(RRT_AABB_TIGHT, kPlain);
-            else if ((need & ~kTextured) == 0) RRT_LAUNCH(RRT_AABB_TIGHT, kTextured);
-            else RRT_LAUNCH(RRT_AABB_TIGHT, F_ALL);
-        }
+#define RRT_LAUNCH(MODE, FEAT, DEEP) hipLaunchKernelGGL((k_trace<MODE, FEAT, DEEP>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt)
+#define RRT_PICK(MODE)                                                               \
+    do {                                                                             \
+        if (s->deep) {                                                               \
+            if ((need & ~kPlain) == 0) RRT_LAUNCH(MODE, kPlain, true);               \
+            else RRT_LAUNCH(MODE, F_ALL, true);                                      \
+        } else if ((need & ~kPlain) == 0) RRT_LAUNCH(MODE, kPlain, false);           \
+        else if ((need & ~kTextured) == 0) RRT_LAUNCH(MODE, kTextured, false);       \
+        else RRT_LAUNCH(MODE, F_ALL, false);                                         \
+    } while (0)
+        if (p->aabb_mode == RRT_AABB_REFERENCE) RRT_PICK(RRT_AABB_REFERENCE);
+        else RRT_PICK(RRT_AABB_TIGHT);
+#undef RRT_PICK
 #undef RRT_LAUNCH
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev[1], st));

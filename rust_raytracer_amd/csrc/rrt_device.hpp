@@ -202,9 +202,9 @@ RRT_DEV f3 xyz(v4f q) { return f3{q.x, q.y, q.z}; }
 
 // ---- device view of the scene ----------------------------------------------------------------------
 struct DScene {
-    const float4* nodes;      // 2 x float4 per rrt_node; a leaf's `a` holds its first PAIR index
+    const float4* nodes;      // 4 x float4 per node: the rrt_node (a leaf's `a` holds its first PAIR index), then the padded
+                              // box its primitives occupy (lo, hi), which the TIGHT traversal tests as well: one 64-byte line
     const float4* pairs;      // 6 x float4 per two consecutive primitives of a leaf (see triangle_pair_hit)
-    const float4* tboxes;     // 2 x float4 per node: the padded box its primitives occupy (TIGHT traversal)
     const float4* slots;      // 3 x float4 per rrt_slot
     const float4* tri_shade;  // 4 x float4 per rrt_tri_shade
     const rrt_sphere* spheres;
@@ -220,7 +220,6 @@ struct DScene {
 
     RRT_DEV cv4p c_nodes() const { return (cv4p)(const void*)nodes; }
     RRT_DEV cv4p c_pairs() const { return (cv4p)(const void*)pairs; }
-    RRT_DEV cv4p c_tboxes() const { return (cv4p)(const void*)tboxes; }
     RRT_DEV cv4p c_slots() const { return (cv4p)(const void*)slots; }
     RRT_DEV cv4p c_tri_shade() const { return (cv4p)(const void*)tri_shade; }
     RRT_DEV cv4p c_btris() const { return (cv4p)(const void*)btris; }
@@ -718,7 +717,6 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
     const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     const cv4p cpairs = sc.c_pairs();
     const cv4p cnodes = sc.c_nodes();
-    const cv4p ctboxes = sc.c_tboxes();
     uint32_t sp = 0;
     uint32_t cur = 0;
 #ifdef RRT_PHASE_PROFILE
@@ -732,12 +730,12 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
 #ifdef RRT_PHASE_PROFILE
         if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_steps;  // first active lane
 #endif
-        const v4f n0 = cnodes[2 * cur];
-        const v4f n1 = cnodes[2 * cur + 1];
+        const v4f n0 = cnodes[4 * cur];
+        const v4f n1 = cnodes[4 * cur + 1];
         bool inside;
         if (sc.is_list) inside = true;
         else if (AABB_MODE == RRT_AABB_TIGHT) {
-            const v4f b0 = ctboxes[2 * cur], b1 = ctboxes[2 * cur + 1];
+            const v4f b0 = cnodes[4 * cur + 2], b1 = cnodes[4 * cur + 3];
             inside = box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
         } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
         if (inside) {
@@ -774,6 +772,172 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
         if (sp == 0) break;
         --sp;
         cur = stack[sp * stride];
+    }
+#ifdef RRT_PHASE_PROFILE
+    atomicAdd(&g_prof[0], prof_nodes);
+    atomicAdd(&g_prof[1], prof_pairs);
+    atomicAdd(&g_prof[2], prof_steps);
+    atomicAdd(&g_prof[3], prof_leaf_steps);
+#endif
+    return h;
+}
+
+// ---- closest hit for deep trees: wave-cooperative leaves ------------------------------------------------------------
+// On a large mesh the lanes of a wave sit in different leaves of very different sizes (1 to 50+ primitives in the
+// reference's trees), and a per-lane leaf loop makes the whole wave wait for every visit.  Here a lane that reaches a leaf
+// only notes it (first pair, pair count) and pauses; when enough lanes are paused (or nobody can walk on) the wave
+// flattens all noted (lane, pair) items into one list and tests them 64 at a time, every lane taking ANY owner's pair:
+// it fetches the owner's ray through the lane crossbar, runs the ordinary pair test against the owner's closest distance,
+// and reduces with a 64-bit minimum on (distance bits, pair position) in the wave's LDS area — the smallest distance wins,
+// equal distances go to the earlier pair, which is what testing the leaf front to back does.  The walk order of every
+// lane is untouched, so results are those of closest_hit.
+//
+// `coop` is this wave's LDS area: 64 x u64 keys followed by 64 x (slot, det, u, v).
+constexpr uint32_t kCoopBytesPerWave = 64 * 8 + 64 * 16;
+#ifndef RRT_COOP_LANES
+#define RRT_COOP_LANES 8
+#endif
+constexpr uint32_t kCoopLanes = RRT_COOP_LANES;  // paused lanes that trigger a cooperative leaf phase
+
+template <uint32_t FEAT>
+RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng& key, uint32_t depth, bool pending, uint32_t first_pair, uint32_t n_pairs,
+                         Hit& h, unsigned char* coop) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long* best = (unsigned long long*)coop;
+    v4f* payload = (v4f*)(coop + 64 * 8);
+    // inclusive prefix sum of the pair counts over the wave (lanes that are not in this call contribute nothing)
+    const uint32_t mine = pending ? n_pairs : 0u;
+    uint32_t incl = mine;
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += up;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    best[lane] = ((unsigned long long)__float_as_uint(h.t) << 32);  // position 0: what the owner already holds wins ties
+    __threadfence_block();
+    const cv4p cpairs = sc.c_pairs();
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t item = base + lane;
+        const bool have = item < total;
+        // owner = first lane whose inclusive sum exceeds the item index
+        uint32_t lo = 0, hi = 63;
+        for (int it = 0; it < 6; ++it) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint32_t v = (uint32_t)__shfl((int)incl, (int)mid);
+            if (v <= item) lo = mid + 1; else hi = mid;
+        }
+        const int owner = (int)(have ? lo : lane);
+        const uint32_t o_incl = (uint32_t)__shfl((int)incl, owner), o_n = (uint32_t)__shfl((int)mine, owner);
+        const uint32_t o_first = (uint32_t)__shfl((int)first_pair, owner);
+        Ray ro;
+        ro.o = mk3(__shfl(r.o.x, owner), __shfl(r.o.y, owner), __shfl(r.o.z, owner));
+        ro.d = mk3(__shfl(r.d.x, owner), __shfl(r.d.y, owner), __shfl(r.d.z, owner));
+        const float o_t = __shfl(h.t, owner);
+        Rng okey = key;
+        uint32_t odepth = depth;
+        if (FEAT & F_MEDIUM) {  // the medium's distance draw is keyed by the owner's stream and depth
+            okey.s0 = (uint32_t)__shfl((int)key.s0, owner);
+            okey.s1 = (uint32_t)__shfl((int)key.s1, owner);
+            odepth = (uint32_t)__shfl((int)depth, owner);
+        }
+        Hit hh;
+        hh.slot = -1;
+        hh.t = o_t;
+        hh.u = hh.v = hh.det = 0.0f;
+        unsigned long long mykey = ~0ull;
+        if (have) {
+            const uint32_t k = item - (o_incl - o_n);  // position of the pair in its leaf
+            test_pair<FEAT>(sc, cpairs + 6 * (o_first + k), ro, t_min, okey, odepth, hh);
+            if (hh.slot >= 0) {
+                mykey = ((unsigned long long)__float_as_uint(hh.t) << 32) | (unsigned long long)(k + 1u);
+                atomicMin(&best[owner], mykey);
+            }
+        }
+        __threadfence_block();
+        if (hh.slot >= 0 && best[owner] == mykey) payload[owner] = v4f{__uint_as_float((uint32_t)hh.slot), hh.det, hh.u, hh.v};
+        __threadfence_block();
+    }
+    if (pending && (uint32_t)best[lane] != 0u) {
+        const v4f w = payload[lane];
+        h.t = __uint_as_float((uint32_t)(best[lane] >> 32));
+        h.slot = (int)__float_as_uint(w.x);
+        h.det = w.y;
+        h.u = w.z;
+        h.v = w.w;
+    }
+}
+
+template <int AABB_MODE, uint32_t FEAT>
+RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack,
+                             uint32_t stride, unsigned char* coop) {
+    // Must be called by all 64 lanes of the wave (the cooperative phase addresses lanes by number); lanes without a ray
+    // pass active = false and only lend a hand.
+    Hit h;
+    h.slot = -1;
+    h.t = t_max;
+    h.u = h.v = h.det = 0.0f;
+    if (sc.n_nodes == 0) return h;
+    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const cv4p cnodes = sc.c_nodes();
+    uint32_t sp = 0, cur = 0;
+    bool running = active, pending = false;
+    uint32_t first_pair = 0, n_pairs = 0;
+#ifdef RRT_PHASE_PROFILE
+    unsigned long long prof_nodes = 0, prof_pairs = 0, prof_steps = 0, prof_leaf_steps = 0;
+#endif
+    for (;;) {
+        if (running) {
+            RRT_COUNT(prof_nodes, 1);
+            const v4f n0 = cnodes[4 * cur];
+            const v4f n1 = cnodes[4 * cur + 1];
+            bool inside;
+            if (sc.is_list) inside = true;
+            else if (AABB_MODE == RRT_AABB_TIGHT) {
+                const v4f b0 = cnodes[4 * cur + 2], b1 = cnodes[4 * cur + 3];
+                inside = box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
+            } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
+            const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
+            if (inside && !(b & RRT_LEAF_FLAG)) {
+                // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
+                const float dax = b == 0u ? r.d.x : (b == 1u ? r.d.y : r.d.z);
+                const uint32_t left = cur + 1u, right = a;
+                const bool left_first = dax < 0.0f;
+                stack[sp * stride] = left_first ? right : left;
+                ++sp;
+                cur = left_first ? left : right;
+            } else if (inside) {
+                pending = true;  // the leaf is tested in the next cooperative phase; the walk resumes after it
+                running = false;
+                first_pair = a;
+                n_pairs = ((b & ~RRT_LEAF_FLAG) + 1u) >> 1;
+                RRT_COUNT(prof_pairs, n_pairs);
+            } else if (sp == 0) {
+                running = false;
+            } else {
+                --sp;
+                cur = stack[sp * stride];
+            }
+        }
+        const unsigned long long waiting = __ballot(pending), walking = __ballot(running);
+#ifdef RRT_PHASE_PROFILE
+        if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_steps;
+#endif
+        if (waiting != 0ull && ((uint32_t)__popcll(waiting) >= kCoopLanes || walking == 0ull)) {
+#ifdef RRT_PHASE_PROFILE
+            if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_leaf_steps;
+#endif
+            coop_leaves<FEAT>(sc, r, t_min, key, depth, pending, first_pair, n_pairs, h, coop);
+            if (pending) {
+                pending = false;
+                if (sp != 0) {
+                    --sp;
+                    cur = stack[sp * stride];
+                    running = true;
+                }
+            }
+        } else if (waiting == 0ull && walking == 0ull) {
+            break;
+        }
     }
 #ifdef RRT_PHASE_PROFILE
     atomicAdd(&g_prof[0], prof_nodes);

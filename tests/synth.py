@@ -41,7 +41,7 @@ def terrain_desc(n, seed=1, width=64, height=64, samples=2, amplitude=0.15, cull
     }
 
 
-def spheres_desc(n=40, seed=3, width=48, height=40, samples=4):
+def spheres_desc(n=40, seed=3, width=48, height=40, samples=4, media=0):
     """Rotated, anisotropically scaled spheres (whose reference bounding box, centre +- radius, ignores the scale and so does
     not contain them), a few with negative radius, over a two-triangle floor; Lambert, Metal, Dielectric and one light."""
     rng = np.random.default_rng(seed)
@@ -53,6 +53,12 @@ def spheres_desc(n=40, seed=3, width=48, height=40, samples=4):
         sc = [float(v) for v in rng.uniform(0.5, 3.0, 3)] if i % 3 else [1.0, 1.0, 1.0]
         radius = float(rng.uniform(0.15, 0.5)) * (-1.0 if i % 11 == 5 else 1.0)
         shapes.append({"type": "sphere", "radius": radius, "material": int(i % 4), "transform": (tr, ro, sc)})
+    for i in range(media):  # constant-density media bounded by (scaled) spheres, Isotropic phase function = material 4
+        tr = [float(v) for v in rng.uniform(-3, 3, 3)]
+        tr[1] = float(rng.uniform(0.5, 2.0))
+        sc = [float(v) for v in rng.uniform(0.8, 2.0, 3)]
+        boundary = {"type": "sphere", "radius": float(rng.uniform(0.4, 0.9)), "material": 0, "transform": (tr, [0.0, 0.0, 0.0], sc)}
+        shapes.insert(int(rng.integers(0, len(shapes))), {"type": "medium", "boundary": boundary, "density": float(rng.uniform(0.5, 3.0)), "phase": 4})
     floor_v = np.array([[-8, 0, -8], [8, 0, -8], [8, 0, 8], [-8, 0, 8]], dtype=np.float64)
     floor_t = np.array([[0, 2, 1], [0, 3, 2]], dtype=np.int32)
     shapes.append({"type": "mesh", "object": {"vertices": floor_v, "tex": np.zeros((0, 2)), "vidx": floor_t, "tidx": np.full_like(floor_t, -1)},
@@ -66,7 +72,8 @@ def spheres_desc(n=40, seed=3, width=48, height=40, samples=4):
         "materials": [{"type": sceneio.MAT_LAMBERT, "albedo": 0, "bump": -1, "param": 0.0},
                       {"type": sceneio.MAT_METAL, "albedo": 1, "bump": -1, "param": 0.2},
                       {"type": sceneio.MAT_DIELECTRIC, "albedo": -1, "bump": -1, "param": 1.5},
-                      {"type": sceneio.MAT_DIFFUSE_LIGHT, "albedo": 2, "bump": -1, "param": 0.0}],
+                      {"type": sceneio.MAT_DIFFUSE_LIGHT, "albedo": 2, "bump": -1, "param": 0.0},
+                      {"type": sceneio.MAT_ISOTROPIC, "albedo": 1, "bump": -1, "param": 0.0}],
         "shapes": shapes,
         "aggregate": 1,
     }
@@ -83,6 +90,12 @@ def host_scene(desc):
     for m in desc["materials"]:
         hs.add_material(m["type"], m["albedo"], m["bump"], m["param"])
     for s in desc["shapes"]:
+        if s["type"] == "medium":
+            b = s["boundary"]
+            assert b["type"] == "sphere"
+            btr, bro, bsc = b["transform"]
+            hs.add_medium_sphere(b["radius"], b["material"], s["density"], s["phase"], btr, bro, bsc)
+            continue
         tr, ro, sc = s["transform"]
         if s["type"] == "sphere":
             hs.add_sphere(s["radius"], s["material"], tr, ro, sc)

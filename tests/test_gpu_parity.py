@@ -159,10 +159,12 @@ def test_mesh_with_a_deep_tree_bit_exact(gpu, cull):
         assert st["rays"] == int(st_ref[0])
 
 
-def test_scaled_spheres_outside_their_reference_boxes_bit_exact(gpu):
+@pytest.mark.parametrize("media", [0, 6])
+def test_scaled_spheres_outside_their_reference_boxes_bit_exact(gpu, media):
     """Sphere::get_bounding_box (shape.rs:129-139) ignores the scale, so scaled spheres stick out of their boxes and the
-    reference misses part of them; both traversal modes must reproduce exactly those hits and misses."""
-    d = synth.spheres_desc()
+    reference misses part of them; both traversal modes must reproduce exactly those hits and misses.  With media the same
+    tree also holds ConstantMedium shapes, whose hit distance is a keyed random draw."""
+    d = synth.spheres_desc(media=media)
     o = orc.OracleScene(d)
     g = rrt.Scene(synth.host_scene(d))
     ro, rd = raygen.ray_batch(o, 48, 40, n_random=8000, seed=4)
