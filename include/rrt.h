@@ -258,7 +258,7 @@ int rrt_render(rrt_scene*, const rrt_render_params* params, float* rgb_sum, rrt_
 int rrt_render_device(rrt_scene*, const rrt_render_params* params, float* d_rgb_sum, uint64_t* d_counters, void* stream);
 
 /* Memory budget of the scene handle's per-sample radiance staging buffer (12 bytes per pixel per sample of a pass;
- * default 4 GiB, 0 restores the default).  A frame whose samples do not fit is traced in several passes; the image
+ * default 16 GiB, 0 restores the default).  A frame whose samples do not fit is traced in several passes; the image
  * does not depend on the split.  No counterpart in the reference (its colours vector, main.rs:115-121, is per pixel). */
 int rrt_scene_set_staging_limit(rrt_scene*, uint64_t bytes);
 

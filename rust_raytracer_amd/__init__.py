@@ -327,7 +327,7 @@ class Scene:
         _check(lib().rrt_render_device(self._h, C.byref(p), d_rgb_sum, d_counters or None, stream or None))
 
     def set_staging_limit(self, nbytes):
-        """Memory budget of the per-sample radiance staging buffer (0 = the 4 GiB default)."""
+        """Memory budget of the per-sample radiance staging buffer (0 = the 16 GiB default)."""
         _check(lib().rrt_scene_set_staging_limit(self._h, nbytes))
 
     def set_timing(self, enable=True):

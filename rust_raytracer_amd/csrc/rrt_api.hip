@@ -16,10 +16,14 @@ namespace {
 
 constexpr int kBlock = 256;              // k_intersect: 4 waves per block
 constexpr int kTraceBlock = 64;          // k_trace: one wave per block, the unit the hardware dispatcher balances
-constexpr uint32_t kChunk = 64;          // samples of each pixel handled by one wave item
+#ifndef RRT_CHUNK
+#define RRT_CHUNK 64
+#endif
+constexpr uint32_t kChunk = RRT_CHUNK;   // samples of each pixel handled by one wave item
 constexpr uint32_t kMaxStackDepth = 64;  // LDS short stack: entries per lane
 constexpr uint32_t kDeepTreeNodes = 16;  // trees with more nodes than this take the cooperative-leaf walk
-constexpr size_t kSlabCapBytes = 4ull << 30;  // per-sample radiance staging buffer (per scene handle, per GPU)
+constexpr size_t kSlabCapBytes = 16ull << 30;  // default budget of the per-sample radiance staging buffer (per scene handle, per GPU):
+                                               // sized for 288 GB of HBM, so that a 1024x1024 frame at 1024 spp is a single pass
 
 struct TraceArgs {
     uint32_t W, H;
