@@ -1,6 +1,7 @@
 // Kernels and the device half of the C ABI (include/rrt.h).
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <limits>
@@ -80,9 +81,9 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
 #else
 #define RRT_TICK(i)
 #endif
-    // DEEP: the closest-hit query is a whole-wave operation, so the loop runs until every lane's pool share is done and
-    // lanes without a path keep taking part (valid = false).
-    while (DEEP ? __ballot(alive) != 0ull : alive) {
+    // The closest-hit query is a whole-wave operation, so the loop runs until every lane's pool share is done and lanes
+    // without a path keep taking part (valid = false).
+    while (__ballot(alive) != 0ull) {
 #ifdef RRT_PHASE_PROFILE
         pc[4] += 1;
         pc[5] += __popcll(__ballot(fresh));
@@ -94,6 +95,13 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
             valid = px < ta.W && py < ta.H;
             if (valid) {
                 g = rng_seed(ta.seed, py * ta.W + px, ta.first_sample + smp);
+                if (RRT_DUP & 32) {
+                    uint32_t p2 = py * ta.W + px;
+                    RRT_OPAQUE(p2);
+                    Rng g2 = rng_seed(ta.seed, p2, ta.first_sample + smp);
+                    Ray r2 = camera_ray(sc.cam, px, py, ta.W, ta.H, g2);
+                    RRT_KEEP(r2.d.x); RRT_KEEP(r2.d.y); RRT_KEEP(r2.d.z); RRT_KEEP(r2.o.x);
+                }
                 r = camera_ray(sc.cam, px, py, ta.W, ta.H, g);
                 thr = mk3(1.0f, 1.0f, 1.0f);
                 depth = 0;
@@ -103,10 +111,17 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
         }
         RRT_TICK(0)
         bool done = true;
-        if (DEEP || valid) {
+        {
             Hit hit;
-            if (DEEP) hit = closest_hit_deep<AABB_MODE, FEAT>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth));
-            else hit = closest_hit<AABB_MODE, FEAT>(sc, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock);
+            unsigned char* area = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
+            if (DEEP) hit = closest_hit_deep<AABB_MODE, FEAT>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area);
+            else hit = closest_hit_sift<AABB_MODE, FEAT>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area);
+            if (!DEEP && (RRT_DUP & 1)) {
+                Ray r2 = r;
+                RRT_OPAQUE(r2.o.x);
+                Hit h2 = closest_hit_sift<AABB_MODE, FEAT>(sc, valid, r2, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area);
+                RRT_KEEP(h2.t); RRT_KEEP(h2.slot); RRT_KEEP(h2.det);
+            }
             RRT_TICK(1)
             if (valid) {
                 ++rays;
@@ -178,7 +193,6 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, const float* __
     extern __shared__ uint32_t lds_stack[];
     size_t i = (size_t)blockIdx.x * kBlock + threadIdx.x;
     const bool active = i < n;
-    if (!DEEP && !active) return;
     Ray r;
     r.o = r.d = mk3(0.0f, 0.0f, 1.0f);
     if (active) {
@@ -191,7 +205,8 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, const float* __
         unsigned char* coop = (unsigned char*)(lds_stack + kBlock * stack_depth) + (threadIdx.x >> 6) * kCoopBytesPerWave;
         h = closest_hit_deep<AABB_MODE, F_ALL>(sc, active, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock, coop);
     } else {
-        h = closest_hit<AABB_MODE, F_ALL>(sc, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock);
+        unsigned char* area = (unsigned char*)(lds_stack + kBlock * stack_depth) + (threadIdx.x >> 6) * kSiftBytesPerWave;
+        h = closest_hit_sift<AABB_MODE, F_ALL>(sc, active, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock, area);
     }
     if (!active) return;
     prim[i] = h.slot >= 0 ? (int)__float_as_uint(sc.slots[3 * h.slot].w) : -1;
@@ -401,62 +416,70 @@ extern "C" {
 // only if the reference's test accepts the reference's box AND the ray overlaps this box: a node rejected by the second
 // condition holds nothing the ray can hit, so the closest hit (and every later decision, which depends only on the
 // closest distance so far) is the reference's.  Two float4 per node: (lo, 0), (hi, 0).
+static float box_pad(const rrt_scene_desc* d) {
+    float scene_max = 0.0f;
+    for (uint32_t i = 0; i < d->n_nodes; ++i)
+        for (int c = 0; c < 3; ++c) scene_max = std::fmax(scene_max, std::fmax(std::fabs(d->nodes[i].bmin[c]), std::fabs(d->nodes[i].bmax[c])));
+    return 1.0e-5f * scene_max + 1.0e-30f;
+}
+// b = (lo.xyz, -, hi.xyz, -)
+static void grow_point(float* b, const float* p) {
+    for (int c = 0; c < 3; ++c) {
+        b[c] = std::fmin(b[c], p[c]);
+        b[4 + c] = std::fmax(b[4 + c], p[c]);
+    }
+}
+static void grow_sphere(float* b, const rrt_sphere& sp) {
+    // corners of the local cube [-|r|, |r|]^3 through local_to_world: their box contains the transformed sphere
+    const float r = std::fabs(sp.radius);
+    for (int k = 0; k < 8; ++k) {
+        const float x = (k & 1) ? r : -r, y = (k & 2) ? r : -r, z = (k & 4) ? r : -r;
+        float p[3];
+        for (int c = 0; c < 3; ++c) p[c] = sp.l2w[4 * c] * x + sp.l2w[4 * c + 1] * y + sp.l2w[4 * c + 2] * z + sp.l2w[4 * c + 3];
+        grow_point(b, p);
+    }
+}
+static void grow_triangle(float* b, const rrt_slot& t) {
+    float v1[3], v2[3];
+    for (int c = 0; c < 3; ++c) {
+        v1[c] = t.v0[c] + t.e1[c];
+        v2[c] = t.v0[c] + t.e2[c];
+    }
+    grow_point(b, t.v0);
+    grow_point(b, v1);
+    grow_point(b, v2);
+}
+// The padded box of `count` consecutive slots starting at `first`.
+static void pair_box(const rrt_scene_desc* d, uint32_t first, uint32_t count, float pad, float* b) {
+    const float inf = std::numeric_limits<float>::infinity();
+    b[0] = b[1] = b[2] = inf;
+    b[4] = b[5] = b[6] = -inf;
+    b[3] = b[7] = 0.0f;
+    for (uint32_t k = 0; k < count; ++k) {
+        const rrt_slot& sl = d->slots[first + k];
+        const uint32_t kind = RRT_INFO_KIND(sl.info);
+        if (kind == RRT_KIND_TRIANGLE) grow_triangle(b, sl);
+        else if (kind == RRT_KIND_SPHERE) grow_sphere(b, d->spheres[sl.aux]);
+        else {
+            const rrt_medium& m = d->media[sl.aux];
+            if (m.boundary_kind == RRT_KIND_SPHERE) grow_sphere(b, d->spheres[m.boundary_index]);
+            else grow_triangle(b, d->boundary_tris[m.boundary_index]);
+        }
+    }
+    for (int c = 0; c < 3; ++c) {
+        b[c] -= pad;
+        b[4 + c] += pad;
+    }
+}
 static std::vector<float> tight_boxes(const rrt_scene_desc* d) {
     const uint32_t n = d->n_nodes;
     std::vector<float> tb((size_t)n * 8, 0.0f);
-    float scene_max = 0.0f;
-    for (uint32_t i = 0; i < n; ++i)
-        for (int c = 0; c < 3; ++c) scene_max = std::fmax(scene_max, std::fmax(std::fabs(d->nodes[i].bmin[c]), std::fabs(d->nodes[i].bmax[c])));
-    const float pad = 1.0e-5f * scene_max + 1.0e-30f;
-    auto grow = [](float* b, const float* p) {
-        for (int c = 0; c < 3; ++c) {
-            b[c] = std::fmin(b[c], p[c]);
-            b[4 + c] = std::fmax(b[4 + c], p[c]);
-        }
-    };
-    auto grow_sphere = [&](float* b, const rrt_sphere& sp) {
-        // corners of the local cube [-|r|, |r|]^3 through local_to_world: their box contains the transformed sphere
-        const float r = std::fabs(sp.radius);
-        for (int k = 0; k < 8; ++k) {
-            const float x = (k & 1) ? r : -r, y = (k & 2) ? r : -r, z = (k & 4) ? r : -r;
-            float p[3];
-            for (int c = 0; c < 3; ++c) p[c] = sp.l2w[4 * c] * x + sp.l2w[4 * c + 1] * y + sp.l2w[4 * c + 2] * z + sp.l2w[4 * c + 3];
-            grow(b, p);
-        }
-    };
-    auto grow_triangle = [&](float* b, const rrt_slot& t) {
-        float v1[3], v2[3];
-        for (int c = 0; c < 3; ++c) {
-            v1[c] = t.v0[c] + t.e1[c];
-            v2[c] = t.v0[c] + t.e2[c];
-        }
-        grow(b, t.v0);
-        grow(b, v1);
-        grow(b, v2);
-    };
+    const float pad = box_pad(d);
     for (uint32_t i = n; i-- > 0;) {  // pre-order layout: children follow their parent
         const rrt_node& nd = d->nodes[i];
         float* b = &tb[(size_t)i * 8];
-        const float inf = std::numeric_limits<float>::infinity();
-        b[0] = b[1] = b[2] = inf;
-        b[4] = b[5] = b[6] = -inf;
         if (nd.b & RRT_LEAF_FLAG) {
-            const uint32_t first = nd.a, count = nd.b & ~RRT_LEAF_FLAG;
-            for (uint32_t k = 0; k < count; ++k) {
-                const rrt_slot& sl = d->slots[first + k];
-                const uint32_t kind = RRT_INFO_KIND(sl.info);
-                if (kind == RRT_KIND_TRIANGLE) grow_triangle(b, sl);
-                else if (kind == RRT_KIND_SPHERE) grow_sphere(b, d->spheres[sl.aux]);
-                else {
-                    const rrt_medium& m = d->media[sl.aux];
-                    if (m.boundary_kind == RRT_KIND_SPHERE) grow_sphere(b, d->spheres[m.boundary_index]);
-                    else grow_triangle(b, d->boundary_tris[m.boundary_index]);
-                }
-            }
-            for (int c = 0; c < 3; ++c) {
-                b[c] -= pad;
-                b[4 + c] += pad;
-            }
+            pair_box(d, nd.a, nd.b & ~RRT_LEAF_FLAG, pad, b);
         } else {
             const float* l = &tb[(size_t)(i + 1) * 8];
             const float* r = &tb[(size_t)nd.a * 8];
@@ -480,33 +503,92 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         rc = upload(src, count, (const void**)&s->d.field, &s->owned);               \
         if (rc) { rrt_scene_destroy(s); return rc; }                                 \
     } while (0)
-    // Device copy of the tree: leaves reference pair records (two primitives interleaved component-wise, 96 bytes).
+    // Device copy of the tree: leaves reference pair records (two primitives interleaved component-wise plus their box,
+    // 128 bytes).  Which primitives share a record is free (every comparison on the device orders hits by distance, then
+    // slot), so each leaf's triangles are matched greedily into the pairs whose common box is smallest: the sifting
+    // traversal tests a pair only when the ray overlaps that box.  Spheres and media get records of their own.
     {
         std::vector<rrt_node> dn(desc->nodes, desc->nodes + desc->n_nodes);
         std::vector<float> pairs;
+        const float pad = box_pad(desc);
         auto put_u = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+        auto emit = [&](uint32_t ia, uint32_t ib, bool has_b) {  // ia < ib: A precedes B in leaf order
+            const rrt_slot& A = desc->slots[ia];
+            const rrt_slot& B = desc->slots[has_b ? ib : ia];
+            const float* av[3] = {A.v0, A.e1, A.e2};
+            const float* bv[3] = {B.v0, B.e1, B.e2};
+            for (int v = 0; v < 3; ++v)
+                for (int c = 0; c < 3; ++c) {
+                    pairs.push_back(av[v][c]);
+                    pairs.push_back(bv[v][c]);
+                }
+            pairs.push_back(put_u(A.info));
+            pairs.push_back(put_u(has_b ? B.info : (RRT_KIND_NONE << 30)));
+            pairs.push_back(put_u(ia));
+            pairs.push_back(put_u(has_b ? ib : ia));
+            pairs.push_back(put_u(A.prim));
+            pairs.push_back(put_u(B.prim));
+            float box[8], box_b[8];
+            pair_box(desc, ia, 1, pad, box);
+            if (has_b) {
+                pair_box(desc, ib, 1, pad, box_b);
+                for (int c = 0; c < 3; ++c) {
+                    box[c] = std::fmin(box[c], box_b[c]);
+                    box[4 + c] = std::fmax(box[4 + c], box_b[4 + c]);
+                }
+            }
+            pairs.insert(pairs.end(), box, box + 8);
+        };
+        auto half_area = [](const float* b) {
+            const float x = b[4] - b[0], y = b[5] - b[1], z = b[6] - b[2];
+            return x * y + y * z + z * x;
+        };
+        std::vector<uint32_t> tri, partner;
+        std::vector<float> boxes;
+        struct Cand { float gain; uint32_t i, j; };
+        std::vector<Cand> cands;
         for (rrt_node& n : dn) {
             if (!(n.b & RRT_LEAF_FLAG)) continue;
             const uint32_t first = n.a, count = n.b & ~RRT_LEAF_FLAG;
-            n.a = (uint32_t)(pairs.size() / 24);
-            for (uint32_t k = 0; k < count; k += 2) {
-                const rrt_slot& A = desc->slots[first + k];
-                const bool has_b = k + 1 < count;
-                const rrt_slot& B = desc->slots[first + (has_b ? k + 1 : k)];
-                const float* av[3] = {A.v0, A.e1, A.e2};
-                const float* bv[3] = {B.v0, B.e1, B.e2};
-                for (int v = 0; v < 3; ++v)
+            const uint32_t first_pair = (uint32_t)(pairs.size() / (4 * kPairQuads));
+            tri.clear();
+            for (uint32_t k = 0; k < count; ++k)
+                if (RRT_INFO_KIND(desc->slots[first + k].info) == RRT_KIND_TRIANGLE) tri.push_back(first + k);
+                else emit(first + k, first + k, false);
+            const uint32_t nt = (uint32_t)tri.size();
+            boxes.resize((size_t)nt * 8);
+            for (uint32_t i = 0; i < nt; ++i) pair_box(desc, tri[i], 1, pad, &boxes[(size_t)i * 8]);
+            // gain of sharing a record = area of the two boxes minus the area of their union (a ray meets a box about in
+            // proportion to its area); best gains first, each triangle used once
+            cands.clear();
+            const uint32_t window = nt <= 256 ? nt : 16;  // huge leaves (a List aggregate over a mesh): nearby slots only
+            for (uint32_t i = 0; i < nt; ++i)
+                for (uint32_t j = i + 1; j < nt && j - i <= window; ++j) {
+                    float u[8];
                     for (int c = 0; c < 3; ++c) {
-                        pairs.push_back(av[v][c]);
-                        pairs.push_back(bv[v][c]);
+                        u[c] = std::fmin(boxes[(size_t)i * 8 + c], boxes[(size_t)j * 8 + c]);
+                        u[4 + c] = std::fmax(boxes[(size_t)i * 8 + 4 + c], boxes[(size_t)j * 8 + 4 + c]);
                     }
-                pairs.push_back(put_u(A.info));
-                pairs.push_back(put_u(has_b ? B.info : (RRT_KIND_NONE << 30)));
-                pairs.push_back(put_u(first + k));
-                pairs.push_back(put_u(first + (has_b ? k + 1 : k)));
-                pairs.push_back(put_u(A.prim));
-                pairs.push_back(put_u(B.prim));
+                    const float gain = half_area(&boxes[(size_t)i * 8]) + half_area(&boxes[(size_t)j * 8]) - half_area(u);
+                    cands.push_back({gain, i, j});
+                }
+            std::stable_sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.gain > y.gain; });
+            partner.assign(nt, 0xffffffffu);
+            float leaf_box[8];
+            pair_box(desc, first, count, pad, leaf_box);
+            const float min_gain = -0.1f * half_area(leaf_box);  // a slightly larger common box still beats a second record
+            for (const Cand& c : cands) {
+                if (c.gain < min_gain) break;
+                if (partner[c.i] != 0xffffffffu || partner[c.j] != 0xffffffffu) continue;
+                partner[c.i] = c.j;
+                partner[c.j] = c.i;
             }
+            for (uint32_t i = 0; i < nt; ++i) {
+                if (partner[i] == 0xffffffffu) emit(tri[i], tri[i], false);
+                else if (partner[i] > i) emit(tri[i], tri[partner[i]], true);
+            }
+            n.a = first_pair;
+            n.b = RRT_LEAF_FLAG | ((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair);
         }
         const std::vector<float> tb = tight_boxes(desc);
         std::vector<float> rec((size_t)dn.size() * 16);  // node (32 bytes) + primitive box (32 bytes) per 64-byte record
@@ -613,7 +695,7 @@ int rrt_intersect_batch_device(rrt_scene* s, const float* d_o, const float* d_d,
     if (n == 0) return RRT_OK;
     if (n > (size_t)0x7fffffff * kBlock) return rrt_set_error(RRT_ERR_LIMIT, "rrt_intersect_batch: too many rays for one launch");
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-    size_t lds = (size_t)kBlock * s->stack_depth * sizeof(uint32_t) + (s->deep ? (size_t)(kBlock / 64) * kCoopBytesPerWave : 0);
+    size_t lds = (size_t)kBlock * s->stack_depth * sizeof(uint32_t) + (size_t)(kBlock / 64) * (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave);
     hipStream_t st = (hipStream_t)stream;
     if (aabb_mode == RRT_AABB_REFERENCE)
         if (s->deep) hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
@@ -714,7 +796,7 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         HIP_TRY(hipMalloc((void**)&s->slab, need_bytes));
         s->slab_bytes = need_bytes;
     }
-    const size_t lds = (size_t)kTraceBlock * s->stack_depth * sizeof(uint32_t) + (s->deep ? kCoopBytesPerWave : 0);
+    const size_t lds = (size_t)kTraceBlock * s->stack_depth * sizeof(uint32_t) + (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave);
     ta.stack_depth = s->stack_depth;
     hipStream_t st = (hipStream_t)stream;
     // compiled variants: plain (triangles + spheres, constant textures), textured (+ textures, bump maps), full (+ media)

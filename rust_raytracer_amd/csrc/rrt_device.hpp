@@ -204,7 +204,7 @@ RRT_DEV f3 xyz(v4f q) { return f3{q.x, q.y, q.z}; }
 struct DScene {
     const float4* nodes;      // 4 x float4 per node: the rrt_node (a leaf's `a` holds its first PAIR index), then the padded
                               // box its primitives occupy (lo, hi), which the TIGHT traversal tests as well: one 64-byte line
-    const float4* pairs;      // 6 x float4 per two consecutive primitives of a leaf (see triangle_pair_hit)
+    const float4* pairs;      // kPairQuads x float4 per two consecutive primitives of a leaf (see triangle_pair_eval)
     const float4* slots;      // 3 x float4 per rrt_slot
     const float4* tri_shade;  // 4 x float4 per rrt_tri_shade
     const rrt_sphere* spheres;
@@ -577,6 +577,14 @@ enum : uint32_t {
 };
 
 
+// Cost-measurement builds only (-DRRT_DUP=<bits>): the named piece is computed a second time on inputs the compiler
+// must treat as new, and the copy's result is kept alive; results are unchanged, the time difference is the piece's cost.
+#ifndef RRT_DUP
+#define RRT_DUP 0
+#endif
+#define RRT_OPAQUE(x) asm volatile("" : "+v"(x))
+#define RRT_KEEP(x) asm volatile("" ::"v"(x))
+
 #ifdef RRT_PHASE_PROFILE
 // profiling build only: per-lane node visits, per-lane pair tests, wave-level node steps, wave-level pair steps
 __device__ unsigned long long g_prof[8];
@@ -627,7 +635,13 @@ RRT_DEV void test_slot(const DScene& sc, uint32_t s, const Ray& r, float t_min, 
 // accepted in leaf order (A, then B against the distance A may have shortened), so the outcome equals two single tests.
 typedef float v2f __attribute__((ext_vector_type(2)));
 RRT_DEV v2f splat2(float x) { return v2f{x, x}; }
-RRT_DEV void triangle_pair_hit(v4f q0, v4f q1, v4f q2, v4f q3, v4f q4, v4f q5, const Ray& r, float t_min, Hit& h) {
+constexpr uint32_t kPairQuads = 8;  // float4 per pair record: six of primitive data, then the padded box of the two primitives (lo, hi)
+struct PairEval {
+    v2f t, u, v, det;
+    bool ok_a, ok_b;  // every acceptance test of Triangle::hit except `t < t_max`
+};
+// Returns false when both determinants were rejected (nothing else is computed then).
+RRT_DEV bool triangle_pair_eval(v4f q0, v4f q1, v4f q2, v4f q3, v4f q4, const Ray& r, float t_min, PairEval& pe) {
     const v2f v0x = q0.xy, v0y = q0.zw, v0z = q1.xy, e1x = q1.zw, e1y = q2.xy, e1z = q2.zw, e2x = q3.xy, e2y = q3.zw, e2z = q4.xy;
     const uint32_t info_a = __float_as_uint(q4.z), info_b = __float_as_uint(q4.w);
     const v2f dx = splat2(r.d.x), dy = splat2(r.d.y), dz = splat2(r.d.z);
@@ -636,7 +650,7 @@ RRT_DEV void triangle_pair_hit(v4f q0, v4f q1, v4f q2, v4f q3, v4f q4, v4f q5, c
     const v2f py = (dz * e2x) - (dx * e2z);
     const v2f pz = (dx * e2y) - (dy * e2x);
     const v2f det = ((e1x * px) + (e1y * py)) + (e1z * pz);
-    // the cull flags are wave-uniform; the common all-culled pair takes a scalar branch to the plain comparisons
+    // the cull flags are wave-uniform in the uniform leaf walk; the common all-culled pair takes a scalar branch to the plain comparisons
     bool ok_a, ok_b;
     if (info_a & info_b & RRT_INFO_CULL) {
         asm volatile("");  // keeps the two arms apart (merged, they cost a per-lane select each)
@@ -646,7 +660,8 @@ RRT_DEV void triangle_pair_hit(v4f q0, v4f q1, v4f q2, v4f q3, v4f q4, v4f q5, c
         ok_a = (info_a & RRT_INFO_CULL) ? !(det.x < RRT_EPS) : !(__builtin_fabsf(det.x) < RRT_EPS);
         ok_b = (info_b & RRT_INFO_CULL) ? !(det.y < RRT_EPS) : !(__builtin_fabsf(det.y) < RRT_EPS);
     }
-    if (!(ok_a || ok_b)) return;
+    pe.ok_a = pe.ok_b = false;
+    if (!(ok_a || ok_b)) return false;
     // 1 / determinant for both triangles: reciprocal estimate + one fused Newton step (see exact_rcp); when the residual of
     // either is not small (zero, denormal, huge or non-finite determinant) the whole wave takes the division instead
     const v2f r0 = v2f{__builtin_amdgcn_rcpf(det.x), __builtin_amdgcn_rcpf(det.y)};
@@ -664,30 +679,33 @@ RRT_DEV void triangle_pair_hit(v4f q0, v4f q1, v4f q2, v4f q3, v4f q4, v4f q5, c
     const v2f uv = u + v;
     const v2f t = (((e2x * qx) + (e2y * qy)) + (e2z * qz)) * inv;
     // acceptance in the reference's order of tests; the comparisons are written so that NaNs fall the same way
-    ok_a = ok_a & !(u.x < 0.0f) & !(u.x > 1.0f) & !(v.x < 0.0f) & !(uv.x > 1.0f) & (t.x > t_min);
-    ok_b = ok_b & !(u.y < 0.0f) & !(u.y > 1.0f) & !(v.y < 0.0f) & !(uv.y > 1.0f) & (t.y > t_min);
+    pe.ok_a = ok_a & !(u.x < 0.0f) & !(u.x > 1.0f) & !(v.x < 0.0f) & !(uv.x > 1.0f) & (t.x > t_min);
+    pe.ok_b = ok_b & !(u.y < 0.0f) & !(u.y > 1.0f) & !(v.y < 0.0f) & !(uv.y > 1.0f) & (t.y > t_min);
+    pe.t = t;
+    pe.u = u;
+    pe.v = v;
+    pe.det = det;
+    return true;
+}
+RRT_DEV void triangle_pair_hit(v4f q0, v4f q1, v4f q2, v4f q3, v4f q4, v4f q5, const Ray& r, float t_min, Hit& h) {
+    PairEval pe;
+    if (!triangle_pair_eval(q0, q1, q2, q3, q4, r, t_min, pe)) return;
     // A first, then B against the distance A may have shortened (leaf order)
-    const bool take_a = ok_a && t.x < h.t;
-    const bool take_b = ok_b && t.y < (take_a ? t.x : h.t);
+    const bool take_a = pe.ok_a && pe.t.x < h.t;
+    const bool take_b = pe.ok_b && pe.t.y < (take_a ? pe.t.x : h.t);
     if (take_a) {
-#ifdef RRT_FORCE_BRANCH
-        asm volatile("");
-#endif
-        h.t = t.x;
+        h.t = pe.t.x;
         h.slot = (int)__float_as_uint(q5.x);
-        h.u = u.x;
-        h.v = v.x;
-        h.det = det.x;
+        h.u = pe.u.x;
+        h.v = pe.v.x;
+        h.det = pe.det.x;
     }
     if (take_b) {
-#ifdef RRT_FORCE_BRANCH
-        asm volatile("");
-#endif
-        h.t = t.y;
+        h.t = pe.t.y;
         h.slot = (int)__float_as_uint(q5.y);
-        h.u = u.y;
-        h.v = v.y;
-        h.det = det.y;
+        h.u = pe.u.y;
+        h.v = pe.v.y;
+        h.det = pe.det.y;
     }
 }
 
@@ -705,82 +723,16 @@ RRT_DEV void test_pair(const DScene& sc, cv4p rec, const Ray& r, float t_min, co
     }
 }
 
-// `stack` points at this lane's first entry of an LDS array laid out [entry][thread]; `stride` = threads per block.
-// Leaves are stored as pair records (6 x float4 per two primitives); a leaf node's `a` is its first pair.
-template <int AABB_MODE, uint32_t FEAT>
-RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack, uint32_t stride) {
-    Hit h;
-    h.slot = -1;
-    h.t = t_max;
-    h.u = h.v = h.det = 0.0f;
-    if (sc.n_nodes == 0) return h;
-    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-    const cv4p cpairs = sc.c_pairs();
-    const cv4p cnodes = sc.c_nodes();
-    uint32_t sp = 0;
-    uint32_t cur = 0;
+// `stack` arguments below point at the calling lane's first entry of an LDS array laid out [entry][thread]; `stride` =
+// threads per block.  Leaves are stored as pair records (kPairQuads x float4 per two primitives); on the device a leaf
+// node's `a` is its first pair and the low bits of `b` its number of pairs.  The two primitives of a pair are in leaf
+// order (A before B) but pairs need not be: every comparison below orders candidates by (distance, slot), and slots are
+// numbered in leaf order.
 #ifdef RRT_PHASE_PROFILE
-    unsigned long long prof_nodes = 0, prof_pairs = 0, prof_steps = 0, prof_leaf_steps = 0;
 #define RRT_COUNT(x, n) x += (n)
 #else
 #define RRT_COUNT(x, n)
 #endif
-    for (;;) {
-        RRT_COUNT(prof_nodes, 1);
-#ifdef RRT_PHASE_PROFILE
-        if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_steps;  // first active lane
-#endif
-        const v4f n0 = cnodes[4 * cur];
-        const v4f n1 = cnodes[4 * cur + 1];
-        bool inside;
-        if (sc.is_list) inside = true;
-        else if (AABB_MODE == RRT_AABB_TIGHT) {
-            const v4f b0 = cnodes[4 * cur + 2], b1 = cnodes[4 * cur + 3];
-            inside = box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
-        } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
-        if (inside) {
-            const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
-            if (b & RRT_LEAF_FLAG) {
-                const uint32_t ua = __builtin_amdgcn_readfirstlane(a), ub = __builtin_amdgcn_readfirstlane(b);
-                if (__ballot(a != ua || b != ub) == 0ull) {
-                    // Every lane that reached a leaf is in the SAME leaf (always so for the one- and few-leaf trees the
-                    // reference builds for small scenes): walk it with wave-uniform indices, so primitive records come
-                    // through the scalar cache into SGPRs and the kind dispatch is a scalar branch.
-                    const uint32_t n_pairs = ((ub & ~RRT_LEAF_FLAG) + 1u) >> 1;
-                    for (uint32_t k = 0; k < n_pairs; ++k) test_pair<FEAT>(sc, cpairs + 6 * (ua + k), r, t_min, key, depth, h);
-                } else {
-                    const uint32_t n_pairs = ((b & ~RRT_LEAF_FLAG) + 1u) >> 1;
-                    RRT_COUNT(prof_pairs, n_pairs);
-                    for (uint32_t k = 0; k < n_pairs; ++k) {
-#ifdef RRT_PHASE_PROFILE
-                        if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_leaf_steps;
-#endif
-                        test_pair<FEAT>(sc, cpairs + 6 * (a + k), r, t_min, key, depth, h);
-                    }
-                }
-            } else {
-                // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
-                const float dax = b == 0u ? r.d.x : (b == 1u ? r.d.y : r.d.z);
-                const uint32_t left = cur + 1u, right = a;
-                const bool left_first = dax < 0.0f;
-                stack[sp * stride] = left_first ? right : left;
-                ++sp;
-                cur = left_first ? left : right;
-                continue;
-            }
-        }
-        if (sp == 0) break;
-        --sp;
-        cur = stack[sp * stride];
-    }
-#ifdef RRT_PHASE_PROFILE
-    atomicAdd(&g_prof[0], prof_nodes);
-    atomicAdd(&g_prof[1], prof_pairs);
-    atomicAdd(&g_prof[2], prof_steps);
-    atomicAdd(&g_prof[3], prof_leaf_steps);
-#endif
-    return h;
-}
 
 // ---- closest hit for deep trees: wave-cooperative leaves ------------------------------------------------------------
 // On a large mesh the lanes of a wave sit in different leaves of very different sizes (1 to 50+ primitives in the
@@ -788,8 +740,8 @@ RRT_DEV Hit closest_hit(const DScene& sc, const Ray& r, float t_min, float t_max
 // only notes it (first pair, pair count) and pauses; when enough lanes are paused (or nobody can walk on) the wave
 // flattens all noted (lane, pair) items into one list and tests them 64 at a time, every lane taking ANY owner's pair:
 // it fetches the owner's ray through the lane crossbar, runs the ordinary pair test against the owner's closest distance,
-// and reduces with a 64-bit minimum on (distance bits, pair position) in the wave's LDS area — the smallest distance wins,
-// equal distances go to the earlier pair, which is what testing the leaf front to back does.  The walk order of every
+// and reduces with a 64-bit minimum on (distance bits, slot) in the wave's LDS area — the smallest distance wins,
+// equal distances go to the earlier slot, which is what testing the leaf front to back does.  The walk order of every
 // lane is untouched, so results are those of closest_hit.
 //
 // `coop` is this wave's LDS area: 64 x u64 keys followed by 64 x (slot, det, u, v).
@@ -847,9 +799,9 @@ RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng&
         unsigned long long mykey = ~0ull;
         if (have) {
             const uint32_t k = item - (o_incl - o_n);  // position of the pair in its leaf
-            test_pair<FEAT>(sc, cpairs + 6 * (o_first + k), ro, t_min, okey, odepth, hh);
+            test_pair<FEAT>(sc, cpairs + kPairQuads * (o_first + k), ro, t_min, okey, odepth, hh);
             if (hh.slot >= 0) {
-                mykey = ((unsigned long long)__float_as_uint(hh.t) << 32) | (unsigned long long)(k + 1u);
+                mykey = ((unsigned long long)__float_as_uint(hh.t) << 32) | (unsigned long long)((uint32_t)hh.slot + 1u);
                 atomicMin(&best[owner], mykey);
             }
         }
@@ -909,7 +861,7 @@ RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float 
                 pending = true;  // the leaf is tested in the next cooperative phase; the walk resumes after it
                 running = false;
                 first_pair = a;
-                n_pairs = ((b & ~RRT_LEAF_FLAG) + 1u) >> 1;
+                n_pairs = b & ~RRT_LEAF_FLAG;
                 RRT_COUNT(prof_pairs, n_pairs);
             } else if (sp == 0) {
                 running = false;
@@ -945,6 +897,208 @@ RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float 
     atomicAdd(&g_prof[2], prof_steps);
     atomicAdd(&g_prof[3], prof_leaf_steps);
 #endif
+    return h;
+}
+
+// Recomputes (u, v, det) the way Triangle::get_hit_properties does (shape.rs:384-400) for callers without a Hit.
+RRT_DEV void triangle_uvdet(f3 v0, f3 e1, f3 e2, const Ray& r, float* u, float* v, float* det) {
+    f3 p_vec = cross3(r.d, e2);
+    float d = dot3(e1, p_vec);
+    float inv_det = 1.0f / d;
+    f3 t_vec = r.o - v0;
+    *u = dot3(t_vec, p_vec) * inv_det;
+    f3 q_vec = cross3(t_vec, e1);
+    *v = dot3(r.d, q_vec) * inv_det;
+    *det = d;
+}
+// ---- closest hit for shallow trees: sift, then test densely ------------------------------------------------------------
+// The reference's trees for small scenes are one or a few big leaves (its SAH rarely splits them), so every ray would run
+// the full test against every primitive.  Here a lane that reaches a leaf pauses; once no lane is walking, the wave
+//  1. sifts: each paused lane tests its ray against the padded box of every pair of its leaf (wave-uniform pair index, box
+//     in scalar registers) and appends an item (pair, lane) to a list in LDS for every box its ray overlaps.  A pair whose
+//     box the ray misses within (t_min, closest so far] holds nothing the ray can hit, so nothing is lost;
+//  2. tests densely: the items are handed out 64 at a time, any lane taking any owner's item: it fetches the owner's ray
+//     through the lane crossbar, runs the exact pair test and posts (distance, slot) with a 64-bit LDS
+//     minimum - the smallest distance wins and equal distances go to the earlier primitive, which is what testing the
+//     leaf front to back with a strict comparison does (aggregate.rs:144-165).
+// The walk order of every lane is the reference's, so results equal closest_hit.
+// `area` is this wave's LDS: 64 x u64 keys, then kSiftCap x u32 items.
+constexpr uint32_t kSiftCap = 512;
+constexpr uint32_t kSiftBytesPerWave = 64 * 8 + kSiftCap * 4;
+
+// monotone map float -> uint (all non-NaN values), and back
+RRT_DEV uint32_t ord_bits(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+RRT_DEV float ord_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+
+template <uint32_t FEAT>
+RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, const uint32_t* items, uint32_t n_items,
+                        unsigned long long* best) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const cv4p cpairs = sc.c_pairs();
+    __threadfence_block();
+    for (uint32_t base = 0; base < n_items; base += 64u) {
+        const uint32_t idx = base + lane;
+        const bool have = idx < n_items;
+        const uint32_t item = have ? items[idx] : lane;
+        const int owner = (int)(item & 63u);
+        const uint32_t pair = item >> 6;
+        Ray ro;
+        ro.o = mk3(__shfl(r.o.x, owner), __shfl(r.o.y, owner), __shfl(r.o.z, owner));
+        ro.d = mk3(__shfl(r.d.x, owner), __shfl(r.d.y, owner), __shfl(r.d.z, owner));
+        Rng okey = key;
+        uint32_t odepth = depth;
+        if (FEAT & F_MEDIUM) {  // the medium's distance draw is keyed by the owner's stream and depth
+            okey.s0 = (uint32_t)__shfl((int)key.s0, owner);
+            okey.s1 = (uint32_t)__shfl((int)key.s1, owner);
+            odepth = (uint32_t)__shfl((int)depth, owner);
+        }
+        if (have) {
+            const cv4p rec = cpairs + kPairQuads * pair;
+            const v4f q4 = rec[4];
+            const uint32_t kind_a = RRT_INFO_KIND(__float_as_uint(q4.z)), kind_b = RRT_INFO_KIND(__float_as_uint(q4.w));
+            const v4f q5 = rec[5];
+            bool found = false, second = false, det_neg = false;
+            float t_found = t_max;
+            if (kind_a == RRT_KIND_TRIANGLE && kind_b == RRT_KIND_TRIANGLE) {
+                PairEval pe;
+                if (triangle_pair_eval(rec[0], rec[1], rec[2], rec[3], q4, ro, t_min, pe)) {
+                    const bool ok_a = pe.ok_a && pe.t.x < t_max, ok_b = pe.ok_b && pe.t.y < t_max;
+                    second = ok_b && !(ok_a && !(pe.t.y < pe.t.x));  // A keeps an equal distance (leaf order)
+                    found = ok_a || ok_b;
+                    t_found = second ? pe.t.y : pe.t.x;
+                    det_neg = (second ? pe.det.y : pe.det.x) < 0.0f;
+                }
+            } else {
+                Hit hh;
+                hh.slot = -1;
+                hh.t = t_max;
+                hh.u = hh.v = hh.det = 0.0f;
+                test_slot<FEAT>(sc, __float_as_uint(q5.x), ro, t_min, okey, odepth, hh);
+                if (kind_b != RRT_KIND_NONE) {
+                    const int before = hh.slot;
+                    const float t_before = hh.t;
+                    test_slot<FEAT>(sc, __float_as_uint(q5.y), ro, t_min, okey, odepth, hh);
+                    second = hh.slot >= 0 && (before < 0 || hh.t < t_before);
+                }
+                found = hh.slot >= 0;
+                t_found = hh.t;
+                det_neg = hh.det < 0.0f;
+            }
+            if (found) {
+                const uint32_t slot = __float_as_uint(second ? q5.y : q5.x);
+                const uint32_t low = ((slot + 1u) << 1) | (det_neg ? 1u : 0u);
+                atomicMin(&best[owner], ((unsigned long long)ord_bits(t_found) << 32) | (unsigned long long)low);
+            }
+        }
+    }
+    __threadfence_block();
+}
+
+template <int AABB_MODE, uint32_t FEAT>
+RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack,
+                             uint32_t stride, unsigned char* area) {
+    // Must be called by all 64 lanes of the wave (the dense phase addresses lanes by number); lanes without a ray pass
+    // active = false and only lend a hand.
+    Hit h;
+    h.slot = -1;
+    h.t = t_max;
+    h.u = h.v = h.det = 0.0f;
+    if (sc.n_nodes == 0) return h;
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long* best = (unsigned long long*)area;
+    uint32_t* items = (uint32_t*)(area + 64 * 8);
+    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const cv4p cnodes = sc.c_nodes();
+    const cv4p cpairs = sc.c_pairs();
+    uint32_t sp = 0, cur = 0;
+    bool running = active, pending = false;
+    uint32_t first_pair = 0, n_pairs = 0;
+    for (;;) {
+        if (running) {
+            const v4f n0 = cnodes[4 * cur];
+            const v4f n1 = cnodes[4 * cur + 1];
+            bool inside;
+            if (sc.is_list) inside = true;
+            else if (AABB_MODE == RRT_AABB_TIGHT) {
+                const v4f b0 = cnodes[4 * cur + 2], b1 = cnodes[4 * cur + 3];
+                inside = box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
+            } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
+            const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
+            if (inside && !(b & RRT_LEAF_FLAG)) {
+                // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
+                const float dax = b == 0u ? r.d.x : (b == 1u ? r.d.y : r.d.z);
+                const uint32_t left = cur + 1u, right = a;
+                const bool left_first = dax < 0.0f;
+                stack[sp * stride] = left_first ? right : left;
+                ++sp;
+                cur = left_first ? left : right;
+            } else if (inside) {
+                pending = true;  // the leaf is tested in the next sift phase; the walk resumes after it
+                running = false;
+                first_pair = a;
+                n_pairs = b & ~RRT_LEAF_FLAG;
+            } else if (sp == 0) {
+                running = false;
+            } else {
+                --sp;
+                cur = stack[sp * stride];
+            }
+        }
+        if (__ballot(running) != 0ull) continue;
+        const unsigned long long waiting = __ballot(pending);
+        if (waiting == 0ull) break;
+        best[lane] = (unsigned long long)ord_bits(h.t) << 32;  // position 0: what the owner already holds wins ties
+        uint32_t n_items = 0;
+        unsigned long long todo = waiting;
+        while (todo != 0ull) {
+            // the paused lanes are grouped by leaf (one group for the single-leaf trees of the small scenes)
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t leaf_first = (uint32_t)__builtin_amdgcn_readlane((int)first_pair, leader);
+            const uint32_t leaf_pairs = (uint32_t)__builtin_amdgcn_readlane((int)n_pairs, leader);
+            const bool mine = pending && first_pair == leaf_first;
+            for (uint32_t k = 0; k < leaf_pairs; ++k) {
+                const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
+                const v4f lo = rec[6], hi = rec[7];
+                const bool pass = mine && box_overlap(xyz(lo), xyz(hi), r.o, inv, t_min, h.t);
+                const unsigned long long bal = __ballot(pass);
+                if (pass) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    items[n_items + rank] = ((leaf_first + k) << 6) | lane;
+                }
+                n_items += (uint32_t)__popcll(bal);
+                if (n_items > kSiftCap - 64u) {
+                    sift_flush<FEAT>(sc, r, t_min, t_max, key, depth, items, n_items, best);
+                    n_items = 0;
+                }
+            }
+            todo &= ~__ballot(mine);
+        }
+        sift_flush<FEAT>(sc, r, t_min, t_max, key, depth, items, n_items, best);
+        if (pending) {
+            const unsigned long long w = best[lane];
+            const uint32_t low = (uint32_t)w;
+            if (low != 0u) {
+                h.t = ord_float((uint32_t)(w >> 32));
+                h.slot = (int)((low >> 1) - 1u);
+                h.det = (low & 1u) ? -1.0f : 1.0f;  // only the sign is used (by the hit properties)
+            }
+            pending = false;
+            if (sp != 0) {
+                --sp;
+                cur = stack[sp * stride];
+                running = true;
+            }
+        }
+    }
+    if ((FEAT & (F_TEX | F_BUMP)) && h.slot >= 0) {
+        // Triangle::get_hit_properties recomputes the barycentrics from the ray (shape.rs:384-400); so does this path
+        const cv4p cslots = sc.c_slots();
+        const v4f q0 = cslots[3 * h.slot], q1 = cslots[3 * h.slot + 1], q2 = cslots[3 * h.slot + 2];
+        if (RRT_INFO_KIND(__float_as_uint(q1.w)) == RRT_KIND_TRIANGLE) triangle_uvdet(xyz(q0), xyz(q1), xyz(q2), r, &h.u, &h.v, &h.det);
+    }
     return h;
 }
 
@@ -1005,17 +1159,6 @@ RRT_DEV HitProps triangle_props(cv4p shade4, const Ray& r, float t_hit, float u,
         h.pu = h.pv = mk3(0.0f, 0.0f, 0.0f);
     }
     return h;
-}
-// Recomputes (u, v, det) the way Triangle::get_hit_properties does (shape.rs:384-400) for callers without a Hit.
-RRT_DEV void triangle_uvdet(f3 v0, f3 e1, f3 e2, const Ray& r, float* u, float* v, float* det) {
-    f3 p_vec = cross3(r.d, e2);
-    float d = dot3(e1, p_vec);
-    float inv_det = 1.0f / d;
-    f3 t_vec = r.o - v0;
-    *u = dot3(t_vec, p_vec) * inv_det;
-    f3 q_vec = cross3(t_vec, e1);
-    *v = dot3(r.d, q_vec) * inv_det;
-    *det = d;
 }
 // Shape::get_hit_properties for whatever sits in `hit.slot`; *material receives Shape::get_material.
 template <uint32_t FEAT>
@@ -1185,6 +1328,13 @@ RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, ui
     }
     uint32_t mat_id;
     HitProps hp = slot_props<FEAT>(sc, hit, r, &mat_id);
+    if (RRT_DUP & 2) {
+        Ray r2 = r;
+        RRT_OPAQUE(r2.o.x);
+        uint32_t m2;
+        HitProps h2 = slot_props<FEAT>(sc, hit, r2, &m2);
+        RRT_KEEP(h2.p.x); RRT_KEEP(h2.p.y); RRT_KEEP(h2.p.z); RRT_KEEP(h2.n.x); RRT_KEEP(h2.n.y); RRT_KEEP(h2.n.z);
+    }
     if (FEAT & (F_TEX | F_BUMP)) {
         hp.u = clampf(hp.u, 0.0f, 1.0f);  // aggregate.rs:31
         hp.v = clampf(hp.v, 0.0f, 1.0f);
@@ -1216,6 +1366,17 @@ RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, ui
             if (rng_f32(g) < reflect_prob) out = reflect_ref(unit_dir, n_use);
             else out = refract_ref(unit_dir, n_use, eta);
         }
+        if (RRT_DUP & 64) {
+            f3 u2 = unit_dir;
+            RRT_OPAQUE(u2.x);
+            float c2 = fmin_ref(dot3(-u2, n_use), 1.0f);
+            float s2 = __builtin_sqrtf(1.0f - c2 * c2);
+            f3 o2;
+            if (eta * s2 > 1.0f) o2 = reflect_ref(u2, n_use);
+            else if (schlick_ref(c2, eta) > 0.5f) o2 = reflect_ref(u2, n_use);
+            else o2 = refract_ref(u2, n_use, eta);
+            RRT_KEEP(o2.x); RRT_KEEP(o2.y); RRT_KEEP(o2.z);
+        }
         thr = thr * mk3(1.0f, 1.0f, 1.0f);
         r.o = hp.p;
         r.d = out;
@@ -1244,11 +1405,29 @@ RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, ui
     f3 att = albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
     Ray scattered;
     scattered.o = hp.p;
+    if (RRT_DUP & 4) {
+        Rng g2 = g;
+        RRT_OPAQUE(g2.s0);
+        f3 d2 = sample_scatter_direction(sc, n, hp.p, g2);
+        RRT_KEEP(d2.x); RRT_KEEP(d2.y); RRT_KEEP(d2.z);
+    }
     scattered.d = sample_scatter_direction(sc, n, hp.p, g);
     const float scatter_pdf = cosine_value(n, scattered);
     float pdf_val;
     if (sc.n_lights > 0) pdf_val = mixture_value(sc, scattered) * 0.5f + scatter_pdf * 0.5f;  // pair_value, pdf.rs:117-119
     else pdf_val = scatter_pdf;
+    if (RRT_DUP & 8) {
+        Ray s2 = scattered;
+        RRT_OPAQUE(s2.d.x);
+        float m2 = mixture_value(sc, s2);
+        RRT_KEEP(m2);
+    }
+    if (RRT_DUP & 16) {
+        Ray s2 = scattered;
+        RRT_OPAQUE(s2.d.x);
+        float m2 = cosine_value(n, s2);
+        RRT_KEEP(m2);
+    }
     thr = (thr * (att * scatter_pdf)) / pdf_val;
     r = scattered;
     return false;
