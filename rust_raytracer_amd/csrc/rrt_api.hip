@@ -83,7 +83,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
 #endif
     // The closest-hit query is a whole-wave operation, so the loop runs until every lane's pool share is done and lanes
     // without a path keep taking part (valid = false).
-    while (__ballot(alive) != 0ull) {
+    while (RRT_BALLOT(alive) != 0ull) {
 #ifdef RRT_PHASE_PROFILE
         pc[4] += 1;
         pc[5] += __popcll(__ballot(fresh));
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
                 }
             }
         }
-        const unsigned long long finished = __ballot(done);
+        const unsigned long long finished = RRT_BALLOT(done);
         if (done) {
             const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(finished >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)finished, 0u));
             idx = next + rank;
@@ -420,6 +420,7 @@ static float box_pad(const rrt_scene_desc* d) {
     float scene_max = 0.0f;
     for (uint32_t i = 0; i < d->n_nodes; ++i)
         for (int c = 0; c < 3; ++c) scene_max = std::fmax(scene_max, std::fmax(std::fabs(d->nodes[i].bmin[c]), std::fabs(d->nodes[i].bmax[c])));
+    for (int c = 0; c < 3; ++c) scene_max = std::fmax(scene_max, std::fabs(d->camera.origin[c]));  // ray origins: the camera or a surface
     return 1.0e-5f * scene_max + 1.0e-30f;
 }
 // b = (lo.xyz, -, hi.xyz, -)
@@ -537,7 +538,8 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                     box[4 + c] = std::fmax(box[4 + c], box_b[4 + c]);
                 }
             }
-            pairs.insert(pairs.end(), box, box + 8);
+            const float inter[8] = {box[0], box[4], box[1], box[5], box[2], box[6], 0.0f, 0.0f};  // (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z)
+            pairs.insert(pairs.end(), inter, inter + 8);
         };
         auto half_area = [](const float* b) {
             const float x = b[4] - b[0], y = b[5] - b[1], z = b[6] - b[2];

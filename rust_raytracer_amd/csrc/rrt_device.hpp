@@ -9,6 +9,7 @@
 #include "../../include/rrt.h"
 
 #define RRT_DEV __device__ __forceinline__
+#define RRT_BALLOT(pred) __builtin_amdgcn_ballot_w64(pred)  // lanes where `pred` holds (the HIP __ballot takes an int and costs two more instructions)
 
 namespace rrt {
 
@@ -565,6 +566,20 @@ RRT_DEV bool box_overlap(f3 lo, f3 hi, f3 o, f3 inv, float t_min, float t_max) {
     return t_near <= t_far;
 }
 
+// The same interval test against a pair record's box, which is stored interleaved (lo.x, hi.x | lo.y, hi.y | lo.z, hi.z) so
+// that both planes of an axis take one packed fused multiply-add: plane * inv + noi with noi = -(origin * inv).  Compared
+// with (plane - origin) * inv the result moves by a few ulps of |origin * inv|, i.e. by a few 1e-7 of the origin's
+// coordinate in space, far inside the padding of the boxes (1e-5 of the scene's extent, camera position included).
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+RRT_DEV bool pair_box_overlap(v2f_ x, v2f_ y, v2f_ z, f3 inv, f3 noi, float t_min, float t_max) {
+    const v2f_ tx = __builtin_elementwise_fma(x, v2f_{inv.x, inv.x}, v2f_{noi.x, noi.x});
+    const v2f_ ty = __builtin_elementwise_fma(y, v2f_{inv.y, inv.y}, v2f_{noi.y, noi.y});
+    const v2f_ tz = __builtin_elementwise_fma(z, v2f_{inv.z, inv.z}, v2f_{noi.z, noi.z});
+    const float t_near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)), __builtin_fmaxf(__builtin_fminf(tz.x, tz.y), t_min));
+    const float t_far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)), __builtin_fminf(__builtin_fmaxf(tz.x, tz.y), t_max));
+    return t_near <= t_far;
+}
+
 // ---- scene features a kernel variant is compiled for ------------------------------------------------------------------
 // The host picks the smallest variant that covers the scene, so scenes without media / image textures / bump maps do not
 // carry that code (registers, instruction cache) through the inner loop.
@@ -587,7 +602,7 @@ enum : uint32_t {
 
 #ifdef RRT_PHASE_PROFILE
 // profiling build only: per-lane node visits, per-lane pair tests, wave-level node steps, wave-level pair steps
-__device__ unsigned long long g_prof[8];
+__device__ unsigned long long g_prof[8];  // [4..7]: sift phase (filter steps, items, dense groups, phases), counted per wave
 #endif
 
 // ---- closest hit: BVH::hit (aggregate.rs:324-401) with List::hit (aggregate.rs:144-165) in the leaves ------------
@@ -1011,6 +1026,15 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
     unsigned long long* best = (unsigned long long*)area;
     uint32_t* items = (uint32_t*)(area + 64 * 8);
     const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    // for the pair boxes: plane * finv + noi (see pair_box_overlap); an axis whose product origin * inv is not finite (zero or
+    // denormal direction component) gets NaN, which the interval test ignores: that axis then constrains nothing
+    f3 finv = inv, noi = mk3(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
+    if (!(__builtin_fabsf(noi.x) < __builtin_inff())) { finv.x = 0.0f; noi.x = __builtin_nanf(""); }
+    if (!(__builtin_fabsf(noi.y) < __builtin_inff())) { finv.y = 0.0f; noi.y = __builtin_nanf(""); }
+    if (!(__builtin_fabsf(noi.z) < __builtin_inff())) { finv.z = 0.0f; noi.z = __builtin_nanf(""); }
+#ifdef RRT_PHASE_PROFILE
+    unsigned long long prof_filter = 0, prof_items = 0, prof_groups = 0, prof_phases = 0;
+#endif
     const cv4p cnodes = sc.c_nodes();
     const cv4p cpairs = sc.c_pairs();
     uint32_t sp = 0, cur = 0;
@@ -1047,8 +1071,8 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                 cur = stack[sp * stride];
             }
         }
-        if (__ballot(running) != 0ull) continue;
-        const unsigned long long waiting = __ballot(pending);
+        if (RRT_BALLOT(running) != 0ull) continue;
+        const unsigned long long waiting = RRT_BALLOT(pending);
         if (waiting == 0ull) break;
         best[lane] = (unsigned long long)ord_bits(h.t) << 32;  // position 0: what the owner already holds wins ties
         uint32_t n_items = 0;
@@ -1061,21 +1085,27 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             const bool mine = pending && first_pair == leaf_first;
             for (uint32_t k = 0; k < leaf_pairs; ++k) {
                 const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
-                const v4f lo = rec[6], hi = rec[7];
-                const bool pass = mine && box_overlap(xyz(lo), xyz(hi), r.o, inv, t_min, h.t);
-                const unsigned long long bal = __ballot(pass);
+                const v4f bx = rec[6], bz = rec[7];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, -, -)
+                const bool pass = mine && pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, h.t);
+                const unsigned long long bal = RRT_BALLOT(pass);
                 if (pass) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                     items[n_items + rank] = ((leaf_first + k) << 6) | lane;
                 }
                 n_items += (uint32_t)__popcll(bal);
+                RRT_COUNT(prof_filter, 1);
                 if (n_items > kSiftCap - 64u) {
+                    RRT_COUNT(prof_items, n_items);
+                    RRT_COUNT(prof_groups, (n_items + 63u) / 64u);
                     sift_flush<FEAT>(sc, r, t_min, t_max, key, depth, items, n_items, best);
                     n_items = 0;
                 }
             }
-            todo &= ~__ballot(mine);
+            todo &= ~RRT_BALLOT(mine);
         }
+        RRT_COUNT(prof_items, n_items);
+        RRT_COUNT(prof_groups, (n_items + 63u) / 64u);
+        RRT_COUNT(prof_phases, 1);
         sift_flush<FEAT>(sc, r, t_min, t_max, key, depth, items, n_items, best);
         if (pending) {
             const unsigned long long w = best[lane];
@@ -1093,6 +1123,14 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             }
         }
     }
+#ifdef RRT_PHASE_PROFILE
+    if (lane == 0) {  // wave-level counts
+        atomicAdd(&g_prof[4], prof_filter);
+        atomicAdd(&g_prof[5], prof_items);
+        atomicAdd(&g_prof[6], prof_groups);
+        atomicAdd(&g_prof[7], prof_phases);
+    }
+#endif
     if ((FEAT & (F_TEX | F_BUMP)) && h.slot >= 0) {
         // Triangle::get_hit_properties recomputes the barycentrics from the ray (shape.rs:384-400); so does this path
         const cv4p cslots = sc.c_slots();

@@ -18,3 +18,12 @@ print("rays %d paths %d wave-iterations %d" % (c[0], c[1], c[6]))
 for i, n in enumerate(["regen", "traverse", "shade", "store+pull"]):
     print("%-10s %6.2f %%  %8.0f cycles per wave-iteration" % (n, 100.0 * c[2 + i] / tot, c[2 + i] / c[6]))
 print("fresh lanes per iteration %.2f, valid lanes %.2f, done lanes %.2f" % (c[7] / c[6], c[8] / c[6], c[9] / c[6]))
+L = rrt.lib()
+if hasattr(L, "rrt_profile_read"):
+    import ctypes
+    import numpy as np
+    out = np.zeros(8, dtype=np.uint64)
+    L.rrt_profile_read(ctypes.c_void_p(out.ctypes.data))
+    if out[7]:
+        print("sift: %.2f filter steps, %.1f items, %.2f dense groups per phase; %.2f phases per wave-iteration" % (
+            out[4] / out[7], out[5] / out[7], out[6] / out[7], out[7] / c[6]))
