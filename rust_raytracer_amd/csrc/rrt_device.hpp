@@ -749,6 +749,13 @@ RRT_DEV void test_pair(const DScene& sc, cv4p rec, const Ray& r, float t_min, co
 #define RRT_COUNT(x, n)
 #endif
 
+// monotone map float -> uint (all non-NaN values), and back
+RRT_DEV uint32_t ord_bits(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+RRT_DEV float ord_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+
 // ---- closest hit for deep trees: wave-cooperative leaves ------------------------------------------------------------
 // On a large mesh the lanes of a wave sit in different leaves of very different sizes (1 to 50+ primitives in the
 // reference's trees), and a per-lane leaf loop makes the whole wave wait for every visit.  Here a lane that reaches a leaf
@@ -780,7 +787,7 @@ RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng&
         if (lane >= off) incl += up;
     }
     const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-    best[lane] = ((unsigned long long)__float_as_uint(h.t) << 32);  // position 0: what the owner already holds wins ties
+    best[lane] = ((unsigned long long)ord_bits(h.t) << 32);  // position 0: what the owner already holds wins ties
     __threadfence_block();
     const cv4p cpairs = sc.c_pairs();
     for (uint32_t base = 0; base < total; base += 64u) {
@@ -816,7 +823,7 @@ RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng&
             const uint32_t k = item - (o_incl - o_n);  // position of the pair in its leaf
             test_pair<FEAT>(sc, cpairs + kPairQuads * (o_first + k), ro, t_min, okey, odepth, hh);
             if (hh.slot >= 0) {
-                mykey = ((unsigned long long)__float_as_uint(hh.t) << 32) | (unsigned long long)((uint32_t)hh.slot + 1u);
+                mykey = ((unsigned long long)ord_bits(hh.t) << 32) | (unsigned long long)((uint32_t)hh.slot + 1u);
                 atomicMin(&best[owner], mykey);
             }
         }
@@ -826,7 +833,7 @@ RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng&
     }
     if (pending && (uint32_t)best[lane] != 0u) {
         const v4f w = payload[lane];
-        h.t = __uint_as_float((uint32_t)(best[lane] >> 32));
+        h.t = ord_float((uint32_t)(best[lane] >> 32));
         h.slot = (int)__float_as_uint(w.x);
         h.det = w.y;
         h.u = w.z;
@@ -940,13 +947,6 @@ RRT_DEV void triangle_uvdet(f3 v0, f3 e1, f3 e2, const Ray& r, float* u, float* 
 // `area` is this wave's LDS: 64 x u64 keys, then kSiftCap x u32 items.
 constexpr uint32_t kSiftCap = 512;
 constexpr uint32_t kSiftBytesPerWave = 64 * 8 + kSiftCap * 4;
-
-// monotone map float -> uint (all non-NaN values), and back
-RRT_DEV uint32_t ord_bits(float f) {
-    const uint32_t b = __float_as_uint(f);
-    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
-}
-RRT_DEV float ord_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
 
 template <uint32_t FEAT>
 RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, const uint32_t* items, uint32_t n_items,

@@ -79,6 +79,47 @@ def spheres_desc(n=40, seed=3, width=48, height=40, samples=4, media=0):
     }
 
 
+def slats_desc(n=40, seed=5, width=40, height=32, samples=3, aggregate=0, spheres=3):
+    """n parallel quads stacked along z (every third one duplicated in place, so that exact distance ties occur and the
+    earlier shape must win), a few spheres between them and a light: every ray along z crosses the boxes of most quads.
+    With aggregate=0 ("List") the whole scene is one leaf."""
+    rng = np.random.default_rng(seed)
+    ident_r, ident_s = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+    quad_t = np.array([[0, 1, 2], [0, 2, 3]], dtype=np.int32)
+    shapes = []
+    for i in range(n):
+        z = -2.0 + 4.0 * i / max(n - 1, 1)
+        w = float(rng.uniform(0.3, 1.2))
+        ox, oy = (float(v) for v in rng.uniform(-0.6, 0.6, 2))
+        v = np.array([[ox - w, oy - w, z], [ox + w, oy - w, z], [ox + w, oy + w, z], [ox - w, oy + w, z]], dtype=np.float64)
+        tilt = [float(rng.uniform(-8, 8)), float(rng.uniform(-8, 8)), 0.0] if i % 4 == 1 else ident_r
+        mesh = {"type": "mesh", "object": {"vertices": v, "tex": np.zeros((0, 2)), "vidx": quad_t, "tidx": np.full_like(quad_t, -1)},
+                "cull": bool(i % 5 == 2), "material": int(i % 3), "transform": ([0.0, 0.0, 0.0], tilt, ident_s)}
+        shapes.append(mesh)
+        if i % 3 == 0:
+            shapes.append(dict(mesh, material=int((i + 1) % 3)))
+    for i in range(spheres):
+        shapes.insert(int(rng.integers(0, len(shapes))),
+                      {"type": "sphere", "radius": float(rng.uniform(0.15, 0.4)), "material": int(i % 3),
+                       "transform": ([float(v) for v in rng.uniform(-1, 1, 3)], ident_r, ident_s)})
+    light_v = np.array([[-0.5, 1.9, -0.5], [0.5, 1.9, -0.5], [0.5, 1.9, 0.5], [-0.5, 1.9, 0.5]], dtype=np.float64)
+    shapes.append({"type": "mesh", "object": {"vertices": light_v, "tex": np.zeros((0, 2)), "vidx": quad_t, "tidx": np.full_like(quad_t, -1)},
+                   "cull": False, "material": 3, "transform": ([0.0, 0.0, 0.0], ident_r, ident_s)})
+    return {
+        "logistics": {"resolution_x": width, "resolution_y": height, "samples": samples, "use_importance_sampling": True},
+        "camera": {"position": [0.3, 0.2, 5.0], "look_at": [0.0, 0.0, 0.0], "up": [0.0, 1.0, 0.0], "fov": 35.0,
+                   "aspect_ratio": width / height, "aperture": 0.0, "focus_distance": 1.0},
+        "textures": [{"type": sceneio.TEX_CONSTANT, "color": [0.7, 0.6, 0.5]}, {"type": sceneio.TEX_CONSTANT, "color": [0.9, 0.9, 0.8]},
+                     {"type": sceneio.TEX_CONSTANT, "color": [6.0, 5.0, 4.0]}],
+        "materials": [{"type": sceneio.MAT_LAMBERT, "albedo": 0, "bump": -1, "param": 0.0},
+                      {"type": sceneio.MAT_METAL, "albedo": 1, "bump": -1, "param": 0.1},
+                      {"type": sceneio.MAT_DIELECTRIC, "albedo": -1, "bump": -1, "param": 1.5},
+                      {"type": sceneio.MAT_DIFFUSE_LIGHT, "albedo": 2, "bump": -1, "param": 0.0}],
+        "shapes": shapes,
+        "aggregate": aggregate,
+    }
+
+
 def host_scene(desc):
     """The product's host-side scene for a neutral description (constant textures, meshes and spheres)."""
     import rust_raytracer_amd as rrt

@@ -183,6 +183,35 @@ def test_scaled_spheres_outside_their_reference_boxes_bit_exact(gpu, media):
         assert st["rays"] == int(st_ref[0])
 
 
+@pytest.mark.parametrize("aggregate,n", [(0, 40), (1, 40), (0, 7)])
+def test_one_big_leaf_with_ties_bit_exact(gpu, aggregate, n):
+    """Stacked quads whose boxes most rays cross (the candidate list of a wave overflows and is flushed in parts), shapes
+    duplicated in place (exact ties: the earlier shape wins), spheres mixed in; as a List and as the reference's BVH; also
+    with a negative lower bound, where hits behind the origin count."""
+    d = synth.slats_desc(n=n, aggregate=aggregate)
+    o = orc.OracleScene(d)
+    g = rrt.Scene(synth.host_scene(d))
+    ro, rd = raygen.ray_batch(o, 40, 32, n_random=6000, seed=11)
+    rng = np.random.default_rng(3)
+    k = 6000
+    zo = np.stack([rng.uniform(-1.5, 1.5, k), rng.uniform(-1.5, 1.5, k), rng.uniform(-3.0, 3.0, k)], axis=1).astype(np.float32)
+    zd = np.stack([rng.normal(0, 0.15, k), rng.normal(0, 0.15, k), rng.choice([-1.0, 1.0], k)], axis=1).astype(np.float32)
+    ro, rd = np.concatenate([ro, zo]), np.concatenate([rd, zd])
+    for t_min in (0.001, -2.5):
+        p_ref, t_ref = o.intersect(ro, rd, t_min=t_min)
+        assert (p_ref >= 0).sum() > 4000
+        for mode in (rrt.AABB_TIGHT, rrt.AABB_REFERENCE):
+            p, t = g.hit(ro, rd, t_min=t_min, aabb_mode=mode)
+            assert np.array_equal(p, p_ref), "primitive ids differ in mode %d: %d rays" % (mode, (p != p_ref).sum())
+            assert np.array_equal(bits(t), bits(t_ref))
+    ref, st_ref = o.render(40, 32, 3, seed=4, bg=rrt.BG_SKY)
+    for mode in (rrt.AABB_TIGHT, rrt.AABB_REFERENCE):
+        img, st = g.render(seed=4, background=rrt.BG_SKY, aabb_mode=mode)
+        same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), "%d of %d values differ (mode %d)" % ((~same).sum(), same.size, mode)
+        assert st["rays"] == int(st_ref[0])
+
+
 def test_render_is_independent_of_the_pass_split_and_of_odd_sizes(gpu):
     """Frames that are no multiple of the 8x8 wave tile, sample counts that are no multiple of the 64-sample chunk, and
     staging budgets that force 1, 5 and 70 passes all give the oracle's bits."""
