@@ -49,7 +49,7 @@ struct TraceArgs {
 #ifndef RRT_TRACE_MIN_WAVES
 #define RRT_TRACE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
-template <int AABB_MODE, uint32_t FEAT, bool DEEP>
+template <int AABB_MODE, uint32_t FEAT, bool DEEP, bool HARVEST = false>
 __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t lane = threadIdx.x;
@@ -74,6 +74,10 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
     Rng g;
     r.o = r.d = thr = mk3(0.0f, 0.0f, 0.0f);
     g.s0 = g.s1 = 0;
+    PendingPdf pend;  // HARVEST: the last diffuse bounce's throughput, waiting for the light densities of the ray it scattered
+    pend.active = false;
+    pend.numerator = mk3(0.0f, 0.0f, 0.0f);
+    pend.scatter_pdf = 0.0f;
 #ifdef RRT_PHASE_PROFILE
     unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #define RRT_TICK(i) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tick_; tick_ = now_; }
@@ -105,6 +109,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
                 r = camera_ray(sc.cam, px, py, ta.W, ta.H, g);
                 thr = mk3(1.0f, 1.0f, 1.0f);
                 depth = 0;
+                pend.active = false;
                 ++paths;
             }
             fresh = false;
@@ -114,19 +119,26 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
         {
             Hit hit;
             unsigned char* area = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
+            float harvest[kHarvestLights];
             if (DEEP) hit = closest_hit_deep<AABB_MODE, FEAT>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area);
-            else hit = closest_hit_sift<AABB_MODE, FEAT>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area);
+            else hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
             if (!DEEP && (RRT_DUP & 1)) {
                 Ray r2 = r;
                 RRT_OPAQUE(r2.o.x);
-                Hit h2 = closest_hit_sift<AABB_MODE, FEAT>(sc, valid, r2, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area);
+                float harvest2[kHarvestLights];
+                Hit h2 = closest_hit_sift<AABB_MODE, FEAT, HARVEST>(sc, valid, r2, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest2);
                 RRT_KEEP(h2.t); RRT_KEEP(h2.slot); RRT_KEEP(h2.det);
             }
             RRT_TICK(1)
             if (valid) {
                 ++rays;
                 f3 radiance;
-                done = shade<FEAT>(sc, hit, r, thr, g, depth, ta.max_depth, ta.bg, &radiance);
+                if (HARVEST && pend.active) {  // aggregate.rs:79-89 for the previous bounce, now that this ray's light distances are known
+                    const float pdf_val = mixture_value_harvested(sc, r, harvest) * 0.5f + pend.scatter_pdf * 0.5f;  // pair_value, pdf.rs:117-119
+                    thr = pend.numerator / pdf_val;
+                    pend.active = false;
+                }
+                done = shade<FEAT, HARVEST>(sc, hit, r, thr, g, depth, ta.max_depth, ta.bg, &radiance, &pend);
                 RRT_TICK(2)
 #ifdef RRT_PHASE_PROFILE
                 pc[6] += __popcll(__ballot(true));
@@ -319,6 +331,7 @@ struct rrt_scene {
     uint32_t res_x = 0, res_y = 0, samples = 0, stack_depth = 1;
     uint32_t features = 0;  // F_* bits the scene needs
     bool deep = false;      // many-node tree: kernels use the cooperative-leaf walk (closest_hit_deep)
+    bool harvest = false;   // single leaf, 1..kHarvestLights lights, each one a primitive of the leaf: light densities come out of the closest-hit query
     uint32_t n_spheres = 0, n_media = 0, n_btris = 0, n_materials = 0, n_textures = 0;
     int device = 0;
     // optional per-kernel timing: three events per pass (before k_trace, between the kernels, after k_accumulate)
@@ -513,6 +526,26 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         std::vector<float> pairs;
         const float pad = box_pad(desc);
         auto put_u = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+        // Harvesting (see HARVEST in rrt_device.hpp) needs a single leaf and every light to be one of its primitives:
+        // a triangle light is the slot with the same vertex data and cull flag, a sphere light the slot of that sphere.
+        std::vector<uint32_t> light_of_slot(desc->n_slots, 0u);  // light number + 1
+        bool harvest = desc->n_nodes == 1 && desc->n_lights >= 1 && desc->n_lights <= kHarvestLights;
+        for (uint32_t i = 0; harvest && i < desc->n_lights; ++i) {
+            const rrt_light& l = desc->lights[i];
+            bool matched = false;
+            for (uint32_t j = 0; j < desc->n_slots && !matched; ++j) {
+                const rrt_slot& sl = desc->slots[j];
+                if (light_of_slot[j] != 0u || RRT_INFO_KIND(sl.info) != l.kind) continue;
+                if (l.kind == RRT_KIND_SPHERE) matched = sl.aux == l.index;
+                else
+                    matched = std::memcmp(sl.v0, l.v0, 12) == 0 && std::memcmp(sl.e1, l.e1, 12) == 0 && std::memcmp(sl.e2, l.e2, 12) == 0 &&
+                              ((sl.info & RRT_INFO_CULL) != 0) == (l.cull != 0);
+                if (matched) light_of_slot[j] = i + 1u;
+            }
+            harvest = matched;
+        }
+        if (!harvest) std::fill(light_of_slot.begin(), light_of_slot.end(), 0u);
+        s->harvest = harvest;
         auto emit = [&](uint32_t ia, uint32_t ib, bool has_b) {  // ia < ib: A precedes B in leaf order
             const rrt_slot& A = desc->slots[ia];
             const rrt_slot& B = desc->slots[has_b ? ib : ia];
@@ -523,8 +556,8 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                     pairs.push_back(av[v][c]);
                     pairs.push_back(bv[v][c]);
                 }
-            pairs.push_back(put_u(A.info));
-            pairs.push_back(put_u(has_b ? B.info : (RRT_KIND_NONE << 30)));
+            pairs.push_back(put_u((A.info & ~(15u << 24)) | (light_of_slot[ia] << 24)));
+            pairs.push_back(put_u(has_b ? ((B.info & ~(15u << 24)) | (light_of_slot[ib] << 24)) : (RRT_KIND_NONE << 30)));
             pairs.push_back(put_u(ia));
             pairs.push_back(put_u(has_b ? ib : ia));
             pairs.push_back(put_u(A.prim));
@@ -538,7 +571,8 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                     box[4 + c] = std::fmax(box[4 + c], box_b[4 + c]);
                 }
             }
-            const float inter[8] = {box[0], box[4], box[1], box[5], box[2], box[6], 0.0f, 0.0f};  // (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z)
+            const bool lit = light_of_slot[ia] != 0u || (has_b && light_of_slot[ib] != 0u);
+            const float inter[8] = {box[0], box[4], box[1], box[5], box[2], box[6], put_u(lit ? 1u : 0u), 0.0f};  // (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, lit)
             pairs.insert(pairs.end(), inter, inter + 8);
         };
         auto half_area = [](const float* b) {
@@ -798,7 +832,7 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         HIP_TRY(hipMalloc((void**)&s->slab, need_bytes));
         s->slab_bytes = need_bytes;
     }
-    const size_t lds = (size_t)kTraceBlock * s->stack_depth * sizeof(uint32_t) + (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave);
+    const size_t lds = (size_t)kTraceBlock * s->stack_depth * sizeof(uint32_t) + (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave + kHarvestBytesPerWave);
     ta.stack_depth = s->stack_depth;
     hipStream_t st = (hipStream_t)stream;
     // compiled variants: plain (triangles + spheres, constant textures), textured (+ textures, bump maps), full (+ media)
@@ -828,7 +862,10 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         if (s->deep) {                                                               \
             if ((need & ~kPlain) == 0) RRT_LAUNCH(MODE, kPlain, true);               \
             else RRT_LAUNCH(MODE, F_ALL, true);                                      \
-        } else if ((need & ~kPlain) == 0) RRT_LAUNCH(MODE, kPlain, false);           \
+        } else if ((need & ~kPlain) == 0) {                                          \
+            if (s->harvest) hipLaunchKernelGGL((k_trace<MODE, kPlain, false, true>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt); \
+            else RRT_LAUNCH(MODE, kPlain, false);                                    \
+        }                                                                            \
         else if ((need & ~kTextured) == 0) RRT_LAUNCH(MODE, kTextured, false);       \
         else RRT_LAUNCH(MODE, F_ALL, false);                                         \
     } while (0)

@@ -944,13 +944,25 @@ RRT_DEV void triangle_uvdet(f3 v0, f3 e1, f3 e2, const Ray& r, float* u, float* 
 //     minimum - the smallest distance wins and equal distances go to the earlier primitive, which is what testing the
 //     leaf front to back with a strict comparison does (aggregate.rs:144-165).
 // The walk order of every lane is the reference's, so results equal closest_hit.
-// `area` is this wave's LDS: 64 x u64 keys, then kSiftCap x u32 items.
+// `area` is this wave's LDS: 64 x u64 keys, then kSiftCap x u32 items (then 64 x kHarvestLights floats when harvesting).
+//
+// HARVEST (single-leaf scenes with a few lights).  After a diffuse bounce the reference evaluates the light mixture's
+// density for the scattered ray, which costs one more intersection test per light (Shape::pdf, shape.rs:141-147, 441-458)
+// - against the very primitives the NEXT closest-hit query of that same ray tests anyway.  With HARVEST the query also
+// reports, per light, the distance at which the ray meets the light's own primitive (any distance in (t_min, t_max), whether
+// or not something nearer hides it, and whether or not the leaf's box test let the ray in: Shape::pdf asks the shape, not
+// the tree), and the caller finishes the previous bounce's throughput from that.  Same tests, same numbers, run once.
 constexpr uint32_t kSiftCap = 512;
+constexpr uint32_t kHarvestLights = 4;
 constexpr uint32_t kSiftBytesPerWave = 64 * 8 + kSiftCap * 4;
+constexpr uint32_t kHarvestBytesPerWave = 64 * kHarvestLights * 4;
+#define RRT_PAIR_LIGHT(info) (((info) >> 24) & 15u)  // device-only bits of a pair record's info words: light number + 1
 
-template <uint32_t FEAT>
+template <uint32_t FEAT, bool HARVEST>
 RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, const uint32_t* items, uint32_t n_items,
                         unsigned long long* best) {
+    constexpr uint32_t kLaneShift = HARVEST ? 7 : 6;  // HARVEST items carry one more bit: the owner only wants its lights
+    float* light_t = (float*)((unsigned char*)best + kSiftBytesPerWave);
     const uint32_t lane = threadIdx.x & 63u;
     const cv4p cpairs = sc.c_pairs();
     __threadfence_block();
@@ -959,7 +971,8 @@ RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max
         const bool have = idx < n_items;
         const uint32_t item = have ? items[idx] : lane;
         const int owner = (int)(item & 63u);
-        const uint32_t pair = item >> 6;
+        const uint32_t pair = item >> kLaneShift;
+        const bool lights_only = HARVEST && (item & 64u) != 0u;
         Ray ro;
         ro.o = mk3(__shfl(r.o.x, owner), __shfl(r.o.y, owner), __shfl(r.o.z, owner));
         ro.d = mk3(__shfl(r.d.x, owner), __shfl(r.d.y, owner), __shfl(r.d.z, owner));
@@ -975,12 +988,17 @@ RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max
             const v4f q4 = rec[4];
             const uint32_t kind_a = RRT_INFO_KIND(__float_as_uint(q4.z)), kind_b = RRT_INFO_KIND(__float_as_uint(q4.w));
             const v4f q5 = rec[5];
+            const uint32_t light_a = HARVEST ? RRT_PAIR_LIGHT(__float_as_uint(q4.z)) : 0u, light_b = HARVEST ? RRT_PAIR_LIGHT(__float_as_uint(q4.w)) : 0u;
             bool found = false, second = false, det_neg = false;
             float t_found = t_max;
             if (kind_a == RRT_KIND_TRIANGLE && kind_b == RRT_KIND_TRIANGLE) {
                 PairEval pe;
                 if (triangle_pair_eval(rec[0], rec[1], rec[2], rec[3], q4, ro, t_min, pe)) {
                     const bool ok_a = pe.ok_a && pe.t.x < t_max, ok_b = pe.ok_b && pe.t.y < t_max;
+                    if (HARVEST && (light_a | light_b) != 0u) {  // Triangle::pdf's own hit test (shape.rs:446): this one
+                        if (light_a != 0u && ok_a) light_t[(uint32_t)owner * kHarvestLights + light_a - 1u] = pe.t.x;
+                        if (light_b != 0u && ok_b) light_t[(uint32_t)owner * kHarvestLights + light_b - 1u] = pe.t.y;
+                    }
                     second = ok_b && !(ok_a && !(pe.t.y < pe.t.x));  // A keeps an equal distance (leaf order)
                     found = ok_a || ok_b;
                     t_found = second ? pe.t.y : pe.t.x;
@@ -992,6 +1010,7 @@ RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max
                 hh.t = t_max;
                 hh.u = hh.v = hh.det = 0.0f;
                 test_slot<FEAT>(sc, __float_as_uint(q5.x), ro, t_min, okey, odepth, hh);
+                if (HARVEST && light_a != 0u && hh.slot >= 0) light_t[(uint32_t)owner * kHarvestLights + light_a - 1u] = hh.t;  // Sphere::pdf, shape.rs:142
                 if (kind_b != RRT_KIND_NONE) {
                     const int before = hh.slot;
                     const float t_before = hh.t;
@@ -1002,7 +1021,7 @@ RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max
                 t_found = hh.t;
                 det_neg = hh.det < 0.0f;
             }
-            if (found) {
+            if (found && !lights_only) {
                 const uint32_t slot = __float_as_uint(second ? q5.y : q5.x);
                 const uint32_t low = ((slot + 1u) << 1) | (det_neg ? 1u : 0u);
                 atomicMin(&best[owner], ((unsigned long long)ord_bits(t_found) << 32) | (unsigned long long)low);
@@ -1012,11 +1031,12 @@ RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max
     __threadfence_block();
 }
 
-template <int AABB_MODE, uint32_t FEAT>
+template <int AABB_MODE, uint32_t FEAT, bool HARVEST = false>
 RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack,
-                             uint32_t stride, unsigned char* area) {
+                             uint32_t stride, unsigned char* area, float* harvest = nullptr) {
     // Must be called by all 64 lanes of the wave (the dense phase addresses lanes by number); lanes without a ray pass
-    // active = false and only lend a hand.
+    // active = false and only lend a hand.  HARVEST: the tree is a single leaf; harvest[i] receives the distance at which the
+    // ray meets light i's primitive, or -1.
     Hit h;
     h.slot = -1;
     h.t = t_max;
@@ -1039,7 +1059,11 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
     const cv4p cpairs = sc.c_pairs();
     uint32_t sp = 0, cur = 0;
     bool running = active, pending = false;
+    bool lights_only = false;  // HARVEST: the leaf's box test failed, so only the lights' own primitives are of interest
     uint32_t first_pair = 0, n_pairs = 0;
+    float* light_t = (float*)(area + kSiftBytesPerWave);
+    if (HARVEST)
+        for (uint32_t i = 0; i < kHarvestLights; ++i) harvest[i] = -1.0f;
     for (;;) {
         if (running) {
             const v4f n0 = cnodes[4 * cur];
@@ -1059,9 +1083,10 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                 stack[sp * stride] = left_first ? right : left;
                 ++sp;
                 cur = left_first ? left : right;
-            } else if (inside) {
+            } else if (inside || HARVEST) {
                 pending = true;  // the leaf is tested in the next sift phase; the walk resumes after it
                 running = false;
+                lights_only = !inside;
                 first_pair = a;
                 n_pairs = b & ~RRT_LEAF_FLAG;
             } else if (sp == 0) {
@@ -1075,6 +1100,8 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
         const unsigned long long waiting = RRT_BALLOT(pending);
         if (waiting == 0ull) break;
         best[lane] = (unsigned long long)ord_bits(h.t) << 32;  // position 0: what the owner already holds wins ties
+        if (HARVEST)
+            for (uint32_t i = 0; i < kHarvestLights; ++i) light_t[lane * kHarvestLights + i] = -1.0f;
         uint32_t n_items = 0;
         unsigned long long todo = waiting;
         while (todo != 0ull) {
@@ -1086,18 +1113,20 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             for (uint32_t k = 0; k < leaf_pairs; ++k) {
                 const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
                 const v4f bx = rec[6], bz = rec[7];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, -, -)
-                const bool pass = mine && pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, h.t);
+                bool pass = mine && pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, h.t);
+                if (HARVEST && __float_as_uint(bz.z) == 0u) pass = pass && !lights_only;  // bz.z: the pair holds a light's primitive
                 const unsigned long long bal = RRT_BALLOT(pass);
                 if (pass) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    items[n_items + rank] = ((leaf_first + k) << 6) | lane;
+                    if (HARVEST) items[n_items + rank] = ((leaf_first + k) << 7) | (lights_only ? 64u : 0u) | lane;
+                    else items[n_items + rank] = ((leaf_first + k) << 6) | lane;
                 }
                 n_items += (uint32_t)__popcll(bal);
                 RRT_COUNT(prof_filter, 1);
                 if (n_items > kSiftCap - 64u) {
                     RRT_COUNT(prof_items, n_items);
                     RRT_COUNT(prof_groups, (n_items + 63u) / 64u);
-                    sift_flush<FEAT>(sc, r, t_min, t_max, key, depth, items, n_items, best);
+                    sift_flush<FEAT, HARVEST>(sc, r, t_min, t_max, key, depth, items, n_items, best);
                     n_items = 0;
                 }
             }
@@ -1106,8 +1135,10 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
         RRT_COUNT(prof_items, n_items);
         RRT_COUNT(prof_groups, (n_items + 63u) / 64u);
         RRT_COUNT(prof_phases, 1);
-        sift_flush<FEAT>(sc, r, t_min, t_max, key, depth, items, n_items, best);
+        sift_flush<FEAT, HARVEST>(sc, r, t_min, t_max, key, depth, items, n_items, best);
         if (pending) {
+            if (HARVEST)
+                for (uint32_t i = 0; i < kHarvestLights; ++i) harvest[i] = light_t[lane * kHarvestLights + i];
             const unsigned long long w = best[lane];
             const uint32_t low = (uint32_t)w;
             if (low != 0u) {
@@ -1246,6 +1277,35 @@ RRT_DEV float mixture_value(const DScene& sc, const Ray& r) {  // Mixture::value
     for (uint32_t i = 0; i < sc.n_lights; ++i) sum += weight * light_pdf(sc, lights + i, r);
     return sum;
 }
+// Mixture::value from harvested light distances: light_pdf without the hit tests, which the closest-hit query of this
+// same ray has already run (harvest[i] = the distance, -1 when the ray misses light i's primitive).
+RRT_DEV float mixture_value_harvested(const DScene& sc, const Ray& r, const float* harvest) {
+    float weight = 1.0f / (float)sc.n_lights;
+    float sum = 0.0f;
+    const clight_p lights = sc.c_lights();
+    for (uint32_t i = 0; i < kHarvestLights; ++i) {
+        if (i >= sc.n_lights) break;
+        const clight_p l = lights + i;
+        float p = 0.0f;
+        if (harvest[i] > 0.0f) {
+            if (l->kind == RRT_KIND_SPHERE) {
+                const csphere_p s = sc.c_spheres() + l->index;
+                Ray lr = xform_ray((cf1p)s->w2l, r);
+                const float radius = s->radius;
+                float cos_theta_max = __builtin_sqrtf(fmax_ref(1.0f - radius * radius / sqlen3(mk3(0.0f, 0.0f, 0.0f) - lr.o), 0.0f));
+                float solid_angle = 2.0f * RRT_PI * (1.0f - cos_theta_max);
+                p = 1.0f / solid_angle;
+            } else {
+                const float t_hit = harvest[i];
+                float dist_squared = t_hit * t_hit * sqlen3(r.d);
+                float cosine = __builtin_fabsf(dot3(r.d, ld3((cf1p)l->nrm)) / len3(r.d));
+                p = dist_squared / (cosine * l->area);
+            }
+        }
+        sum += weight * p;
+    }
+    return sum;
+}
 RRT_DEV float cosine_value(f3 normal, const Ray& r) {  // pdf.rs:51-58
     float cosine = dot3(norm3(r.d), normal);
     return cosine < 0.0f ? 0.0f : cosine / RRT_PI;
@@ -1358,8 +1418,15 @@ RRT_DEV Ray camera_ray(const rrt_camera& c, uint32_t x, uint32_t y, uint32_t W, 
 // One step of aggregate::trace (aggregate.rs:26-104) after the closest-hit query, in loop form: either the path ends
 // with a radiance value (`*radiance`, to be weighted by the throughput) or the ray and throughput are advanced.
 // Returns true when the path ended.
-template <uint32_t FEAT>
-RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, uint32_t depth, uint32_t max_depth, uint32_t bg, f3* radiance) {
+// Pending throughput update of a diffuse bounce whose mixture density is still to come (see HARVEST above).
+struct PendingPdf {
+    bool active;
+    f3 numerator;       // throughput * (attenuation * scattering_pdf)
+    float scatter_pdf;  // the cosine lobe's density for the scattered ray
+};
+template <uint32_t FEAT, bool HARVEST = false>
+RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, uint32_t depth, uint32_t max_depth, uint32_t bg, f3* radiance,
+                   PendingPdf* pend = nullptr) {
     if (!(depth < max_depth && hit.slot >= 0)) {
         *radiance = background(bg, r);
         return true;
@@ -1451,6 +1518,13 @@ RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, ui
     }
     scattered.d = sample_scatter_direction(sc, n, hp.p, g);
     const float scatter_pdf = cosine_value(n, scattered);
+    if (HARVEST) {  // n_lights > 0 here; the division by pair_value happens after the next closest-hit query
+        pend->active = true;
+        pend->numerator = thr * (att * scatter_pdf);
+        pend->scatter_pdf = scatter_pdf;
+        r = scattered;
+        return false;
+    }
     float pdf_val;
     if (sc.n_lights > 0) pdf_val = mixture_value(sc, scattered) * 0.5f + scatter_pdf * 0.5f;  // pair_value, pdf.rs:117-119
     else pdf_val = scatter_pdf;
