@@ -230,8 +230,11 @@ int rrt_host_add_medium_sphere(rrt_host_scene*, const float translate[3], const 
 int rrt_host_set_camera(rrt_host_scene*, const float position[3], const float look_at[3], const float up[3], float fov, float aspect,
                         float aperture, float focus_distance); /* camera.rs:66-88 */
 int rrt_host_set_logistics(rrt_host_scene*, uint32_t resolution_x, uint32_t resolution_y, uint32_t samples, int use_importance_sampling);
-/* Builds the light list (scene.rs:130-140), the aggregate (scene.rs:605-619; aggregate.rs:187-322) and the flattened arrays. */
-int rrt_host_finalize(rrt_host_scene*, int aggregate_is_bvh);
+/* Builds the light list (scene.rs:130-140), the aggregate (scene.rs:605-619; aggregate.rs:187-322) and the flattened arrays.
+ * RRT_AGGREGATE_BVH_GPU builds the same tree, bit for bit, on the current device (one sort and four scans per tree level
+ * instead of the reference's recursive re-sorting); it needs a GPU, the other two do not. */
+enum { RRT_AGGREGATE_LIST = 0 /* aggregate.rs:142-165 */, RRT_AGGREGATE_BVH = 1 /* aggregate.rs:187-322 on the host */, RRT_AGGREGATE_BVH_GPU = 2 };
+int rrt_host_finalize(rrt_host_scene*, int aggregate);
 const rrt_scene_desc* rrt_host_desc(const rrt_host_scene*); /* valid after finalize/load, owned by the handle */
 void rrt_host_scene_destroy(rrt_host_scene*);
 

@@ -211,7 +211,7 @@ class HostScene:
         _check(lib().rrt_host_set_logistics(self._h, resolution_x, resolution_y, samples, 1 if use_importance_sampling else 0))
 
     def finalize(self, aggregate="BVH"):
-        _check(lib().rrt_host_finalize(self._h, 1 if aggregate == "BVH" else 0))
+        _check(lib().rrt_host_finalize(self._h, {"List": 0, "BVH": 1, "BVH_GPU": 2}[aggregate]))
 
     @property
     def desc(self):

@@ -1,5 +1,6 @@
 // Scene construction on the host: shapes, light list, SAH BVH, and the flattened device layout.
 #include "scene_host.hpp"
+#include "../rrt_bvh_build.hpp"
 
 #include <algorithm>
 #include <cmath>
@@ -301,13 +302,22 @@ void fill_tri_slot(const HostShape& s, uint32_t prim, rrt_slot* slot, rrt_tri_sh
 }
 }  // namespace
 
-std::string SceneBuild::finalize(bool bvh) {
+std::string SceneBuild::finalize(int aggregate) {
     if (materials.size() > 0x00ffffffu) return "too many materials";
+    const bool bvh = aggregate != RRT_AGGREGATE_LIST;
     BuildCtx cx;
     cx.shapes = &shapes;
     cx.order.resize(shapes.size());
     std::iota(cx.order.begin(), cx.order.end(), 0u);
-    if (bvh) {
+    if (aggregate == RRT_AGGREGATE_BVH_GPU) {
+        // the same tree, built level by level on the current device (rrt_bvh_build.hip)
+        std::vector<float> boxes(shapes.size() * 6);
+        for (size_t i = 0; i < shapes.size(); ++i) {
+            put3(&boxes[i * 6], shapes[i].box.lo);
+            put3(&boxes[i * 6 + 3], shapes[i].box.hi);
+        }
+        if (rrt_bvh_build_gpu(boxes.data(), (uint32_t)shapes.size(), &cx.nodes, &cx.leaf_order, &cx.max_pending) != RRT_OK) return rrt_last_error();
+    } else if (bvh) {
         if (!shapes.empty()) build_range(cx, 0, shapes.size(), 0);  // an empty BVH has no nodes (aggregate.rs:339-341)
     } else {
         // "List" (scene.rs:610): one leaf, scene order, no bounding-box test
@@ -459,9 +469,10 @@ int rrt_host_set_logistics(rrt_host_scene* s, uint32_t rx, uint32_t ry, uint32_t
     s->b.res_x = rx; s->b.res_y = ry; s->b.samples = samples; s->b.use_importance = use_is != 0;
     return RRT_OK;
 }
-int rrt_host_finalize(rrt_host_scene* s, int bvh) {
+int rrt_host_finalize(rrt_host_scene* s, int aggregate) {
     RRT_NEED(s);
-    std::string e = s->b.finalize(bvh != 0);
+    RRT_NEED(aggregate >= RRT_AGGREGATE_LIST && aggregate <= RRT_AGGREGATE_BVH_GPU);
+    std::string e = s->b.finalize(aggregate);
     return e.empty() ? RRT_OK : fail_scene(e);
 }
 const rrt_scene_desc* rrt_host_desc(const rrt_host_scene* s) {

@@ -54,7 +54,7 @@ struct SceneBuild {
     std::string add_medium_sphere(Vec3 tr, Vec3 rot, Vec3 scl, float radius, int32_t boundary_material, float density, int32_t phase);
     std::string add_medium_last_boundary_triangle(float density, int32_t phase);
     void set_camera(Vec3 pos, Vec3 look_at, Vec3 up, float fov, float aspect, float aperture, float focus);
-    std::string finalize(bool bvh);
+    std::string finalize(int aggregate);  // RRT_AGGREGATE_*
 };
 
 // scene file -> SceneBuild (scene.rs:64-159); returns "" or the error text

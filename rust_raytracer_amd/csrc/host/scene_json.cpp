@@ -496,7 +496,7 @@ std::string load_scene_file(const std::string& path, uint32_t ow, uint32_t oh, u
         const Json& agg = required(top, "Aggregate");
         if (agg.kind != Json::String) bail("'Aggregate' is not a string.");
         if (agg.str != "List" && agg.str != "BVH") bail("Unknown Aggregate 'type' " + agg.str + " given.");
-        std::string e = out->finalize(agg.str == "BVH");
+        std::string e = out->finalize(agg.str == "BVH" ? RRT_AGGREGATE_BVH : RRT_AGGREGATE_LIST);
         if (!e.empty()) bail(e);
     } catch (const LoadError& e) {
         return e.msg;

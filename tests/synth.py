@@ -120,8 +120,9 @@ def slats_desc(n=40, seed=5, width=40, height=32, samples=3, aggregate=0, sphere
     }
 
 
-def host_scene(desc):
-    """The product's host-side scene for a neutral description (constant textures, meshes and spheres)."""
+def host_scene(desc, aggregate=None):
+    """The product's host-side scene for a neutral description (constant textures, meshes and spheres).
+    aggregate: "List", "BVH" (built on the host) or "BVH_GPU" (built on the device); default: what the description asks for."""
     import rust_raytracer_amd as rrt
 
     hs = rrt.HostScene.new()
@@ -147,5 +148,5 @@ def host_scene(desc):
     hs.set_camera(c["position"], c["look_at"], c["up"], c["fov"], c["aspect_ratio"], c["aperture"], c["focus_distance"])
     lg = desc["logistics"]
     hs.set_logistics(lg["resolution_x"], lg["resolution_y"], lg["samples"], lg["use_importance_sampling"])
-    hs.finalize("BVH" if desc["aggregate"] else "List")
+    hs.finalize(aggregate or ("BVH" if desc["aggregate"] else "List"))
     return hs

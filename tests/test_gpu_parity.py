@@ -212,6 +212,37 @@ def test_one_big_leaf_with_ties_bit_exact(gpu, aggregate, n):
         assert st["rays"] == int(st_ref[0])
 
 
+def _same_records(a, b):
+    return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
+
+
+@pytest.mark.parametrize("case", ["terrain20k", "terrain180k", "spheres", "slats", "cornell", "tiny2", "tiny6", "tiny8"])
+def test_gpu_built_bvh_equals_the_host_built_one(gpu, case):
+    """RRT_AGGREGATE_BVH_GPU must give the reference's tree bit for bit: node boxes (signed zeros included), cut axes, child
+    links, leaf ranges and the order of the shapes in the leaves, also where box centres tie (the sort must be stable)."""
+    import sceneio
+    if case == "terrain20k":
+        d = synth.terrain_desc(100, seed=2)
+    elif case == "terrain180k":
+        d = synth.terrain_desc(300, seed=5)
+    elif case == "spheres":
+        d = synth.spheres_desc(media=6)
+    elif case == "slats":
+        d = synth.slats_desc(n=40, aggregate=1)
+    elif case == "cornell":
+        d = sceneio.read_scene(orc.asset("Cornell_Box_With_Sphere.json"))
+    else:
+        d = synth.slats_desc(n=2 if case == "tiny8" else 1, aggregate=1, spheres=0)  # 4 or 3 quads
+        if case == "tiny2":
+            d["shapes"] = d["shapes"][:1]  # two triangles: a leaf without any sorting (aggregate.rs:204)
+    host = synth.host_scene(d, "BVH")
+    dev = synth.host_scene(d, "BVH_GPU")
+    assert len(host.nodes()) == len(dev.nodes())
+    assert _same_records(host.nodes(), dev.nodes())
+    assert _same_records(host.slots(), dev.slots())
+    assert host.desc.bvh_depth == dev.desc.bvh_depth
+
+
 def test_render_is_independent_of_the_pass_split_and_of_odd_sizes(gpu):
     """Frames that are no multiple of the 8x8 wave tile, sample counts that are no multiple of the 64-sample chunk, and
     staging budgets that force 1, 5 and 70 passes all give the oracle's bits."""
