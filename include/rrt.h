@@ -176,7 +176,9 @@ typedef struct rrt_scene_desc {
     rrt_camera camera;
     uint32_t resolution_x, resolution_y, samples; /* Logistics, scene.rs:28-34 */
     uint32_t bvh_depth;                           /* maximum number of simultaneously pending stack entries + 1 */
-    uint32_t aggregate_is_list;                   /* "Aggregate": "List" (scene.rs:610): one leaf holding every shape in scene order */
+    uint32_t aggregate_kind;                      /* RRT_AGGREGATE_LIST ("Aggregate": "List", scene.rs:610: one leaf holding every shape in scene
+                                                     order, no box test), RRT_AGGREGATE_BVH (the reference's tree, wherever it was built) or
+                                                     RRT_AGGREGATE_BVH_CLEAN (see rrt_host_finalize) */
 } rrt_scene_desc;
 
 typedef struct rrt_scene rrt_scene; /* device-resident scene */
@@ -231,9 +233,20 @@ int rrt_host_set_camera(rrt_host_scene*, const float position[3], const float lo
                         float aperture, float focus_distance); /* camera.rs:66-88 */
 int rrt_host_set_logistics(rrt_host_scene*, uint32_t resolution_x, uint32_t resolution_y, uint32_t samples, int use_importance_sampling);
 /* Builds the light list (scene.rs:130-140), the aggregate (scene.rs:605-619; aggregate.rs:187-322) and the flattened arrays.
- * RRT_AGGREGATE_BVH_GPU builds the same tree, bit for bit, on the current device (one sort and four scans per tree level
- * instead of the reference's recursive re-sorting); it needs a GPU, the other two do not. */
-enum { RRT_AGGREGATE_LIST = 0 /* aggregate.rs:142-165 */, RRT_AGGREGATE_BVH = 1 /* aggregate.rs:187-322 on the host */, RRT_AGGREGATE_BVH_GPU = 2 };
+ * RRT_AGGREGATE_BVH_GPU builds the reference's tree, bit for bit, on the current device (one sort and four scans per tree
+ * level instead of the reference's recursive re-sorting).
+ * RRT_AGGREGATE_BVH_CLEAN (no counterpart in the reference; for large meshes) builds, also on the device, the tree the
+ * reference's sweep yields WITHOUT its two slips (bounds that always include the world origin, aggregate.rs:195; suffix bounds
+ * that leave out the last shape, aggregate.rs:247-252) and makes queries return what the reference's LIST aggregate returns:
+ * the nearest hit, equal distances going to the shape that is first in scene order.  That differs from the reference's BVH
+ * only where its box test prunes on an exact coincidence or a tie is met in another order (a handful of rays in a million on
+ * meshes), and costs a small fraction of the node visits.  The two _GPU/_CLEAN kinds need a GPU, the first two do not. */
+enum {
+    RRT_AGGREGATE_LIST = 0 /* aggregate.rs:142-165 */,
+    RRT_AGGREGATE_BVH = 1 /* aggregate.rs:187-322 on the host */,
+    RRT_AGGREGATE_BVH_GPU = 2,
+    RRT_AGGREGATE_BVH_CLEAN = 3
+};
 int rrt_host_finalize(rrt_host_scene*, int aggregate);
 const rrt_scene_desc* rrt_host_desc(const rrt_host_scene*); /* valid after finalize/load, owned by the handle */
 void rrt_host_scene_destroy(rrt_host_scene*);

@@ -77,7 +77,7 @@ class _SceneDesc(C.Structure):
                 ("boundary_tri_shade", C.POINTER(_TriShade)), ("n_materials", C.c_uint32), ("materials", C.POINTER(_Material)),
                 ("n_textures", C.c_uint32), ("textures", C.POINTER(_Texture)), ("texel_bytes", C.c_uint64), ("texels", C.POINTER(C.c_uint8)),
                 ("n_lights", C.c_uint32), ("lights", C.POINTER(_Light)), ("camera", _Camera), ("resolution_x", C.c_uint32),
-                ("resolution_y", C.c_uint32), ("samples", C.c_uint32), ("bvh_depth", C.c_uint32), ("aggregate_is_list", C.c_uint32)]
+                ("resolution_y", C.c_uint32), ("samples", C.c_uint32), ("bvh_depth", C.c_uint32), ("aggregate_kind", C.c_uint32)]
 
 
 class _RenderParams(C.Structure):
@@ -211,7 +211,7 @@ class HostScene:
         _check(lib().rrt_host_set_logistics(self._h, resolution_x, resolution_y, samples, 1 if use_importance_sampling else 0))
 
     def finalize(self, aggregate="BVH"):
-        _check(lib().rrt_host_finalize(self._h, {"List": 0, "BVH": 1, "BVH_GPU": 2}[aggregate]))
+        _check(lib().rrt_host_finalize(self._h, {"List": 0, "BVH": 1, "BVH_GPU": 2, "BVH_CLEAN": 3}[aggregate]))
 
     @property
     def desc(self):

@@ -309,14 +309,15 @@ std::string SceneBuild::finalize(int aggregate) {
     cx.shapes = &shapes;
     cx.order.resize(shapes.size());
     std::iota(cx.order.begin(), cx.order.end(), 0u);
-    if (aggregate == RRT_AGGREGATE_BVH_GPU) {
+    if (aggregate == RRT_AGGREGATE_BVH_GPU || aggregate == RRT_AGGREGATE_BVH_CLEAN) {
         // the same tree, built level by level on the current device (rrt_bvh_build.hip)
         std::vector<float> boxes(shapes.size() * 6);
         for (size_t i = 0; i < shapes.size(); ++i) {
             put3(&boxes[i * 6], shapes[i].box.lo);
             put3(&boxes[i * 6 + 3], shapes[i].box.hi);
         }
-        if (rrt_bvh_build_gpu(boxes.data(), (uint32_t)shapes.size(), &cx.nodes, &cx.leaf_order, &cx.max_pending) != RRT_OK) return rrt_last_error();
+        if (rrt_bvh_build_gpu(boxes.data(), (uint32_t)shapes.size(), aggregate == RRT_AGGREGATE_BVH_CLEAN, &cx.nodes, &cx.leaf_order, &cx.max_pending) != RRT_OK)
+            return rrt_last_error();
     } else if (bvh) {
         if (!shapes.empty()) build_range(cx, 0, shapes.size(), 0);  // an empty BVH has no nodes (aggregate.rs:339-341)
     } else {
@@ -391,7 +392,7 @@ std::string SceneBuild::finalize(int aggregate) {
     desc.camera = camera;
     desc.resolution_x = res_x; desc.resolution_y = res_y; desc.samples = samples;
     desc.bvh_depth = cx.max_pending + 1;
-    desc.aggregate_is_list = bvh ? 0u : 1u;
+    desc.aggregate_kind = aggregate == RRT_AGGREGATE_BVH_GPU ? (uint32_t)RRT_AGGREGATE_BVH : (uint32_t)aggregate;
     finalized = true;
     return "";
 }
@@ -471,7 +472,7 @@ int rrt_host_set_logistics(rrt_host_scene* s, uint32_t rx, uint32_t ry, uint32_t
 }
 int rrt_host_finalize(rrt_host_scene* s, int aggregate) {
     RRT_NEED(s);
-    RRT_NEED(aggregate >= RRT_AGGREGATE_LIST && aggregate <= RRT_AGGREGATE_BVH_GPU);
+    RRT_NEED(aggregate >= RRT_AGGREGATE_LIST && aggregate <= RRT_AGGREGATE_BVH_CLEAN);
     std::string e = s->b.finalize(aggregate);
     return e.empty() ? RRT_OK : fail_scene(e);
 }

@@ -331,6 +331,7 @@ struct rrt_scene {
     uint32_t res_x = 0, res_y = 0, samples = 0, stack_depth = 1;
     uint32_t features = 0;  // F_* bits the scene needs
     bool deep = false;      // many-node tree: kernels use the cooperative-leaf walk (closest_hit_deep)
+    bool clean = false;     // tree built with RRT_AGGREGATE_BVH_CLEAN: traversal mode kAabbClean, whatever the caller asks for
     bool harvest = false;   // single leaf, 1..kHarvestLights lights, each one a primitive of the leaf: light densities come out of the closest-hit query
     uint32_t n_spheres = 0, n_media = 0, n_btris = 0, n_materials = 0, n_textures = 0;
     int device = 0;
@@ -352,6 +353,7 @@ static int validate_desc(const rrt_scene_desc* d) {
     if (d->texel_bytes && !d->texels) BAD("texels is NULL");
     if (d->n_lights && !d->lights) BAD("lights is NULL");
     if (d->n_slots && !d->n_nodes) BAD("slots without nodes");
+    if (d->aggregate_kind > RRT_AGGREGATE_BVH_CLEAN) BAD("unknown aggregate kind");
     // Every index a kernel will follow is checked here, once, so that no launch can read out of bounds.
     for (uint32_t i = 0; i < d->n_nodes; ++i) {
         const rrt_node& n = d->nodes[i];
@@ -529,7 +531,7 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         // Harvesting (see HARVEST in rrt_device.hpp) needs a single leaf and every light to be one of its primitives:
         // a triangle light is the slot with the same vertex data and cull flag, a sphere light the slot of that sphere.
         std::vector<uint32_t> light_of_slot(desc->n_slots, 0u);  // light number + 1
-        bool harvest = desc->n_nodes == 1 && desc->n_lights >= 1 && desc->n_lights <= kHarvestLights;
+        bool harvest = desc->n_nodes == 1 && desc->n_lights >= 1 && desc->n_lights <= kHarvestLights && desc->aggregate_kind != RRT_AGGREGATE_BVH_CLEAN;
         for (uint32_t i = 0; harvest && i < desc->n_lights; ++i) {
             const rrt_light& l = desc->lights[i];
             bool matched = false;
@@ -546,7 +548,9 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         }
         if (!harvest) std::fill(light_of_slot.begin(), light_of_slot.end(), 0u);
         s->harvest = harvest;
+        const bool clean = desc->aggregate_kind == RRT_AGGREGATE_BVH_CLEAN;
         auto emit = [&](uint32_t ia, uint32_t ib, bool has_b) {  // ia < ib: A precedes B in leaf order
+            if (clean && has_b && desc->slots[ib].prim < desc->slots[ia].prim) std::swap(ia, ib);  // clean trees: A first in SCENE order
             const rrt_slot& A = desc->slots[ia];
             const rrt_slot& B = desc->slots[has_b ? ib : ia];
             const float* av[3] = {A.v0, A.e1, A.e2};
@@ -649,14 +653,15 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     s->d.n_nodes = desc->n_nodes;
     s->d.n_slots = desc->n_slots;
     s->d.n_lights = desc->n_lights;
-    s->d.is_list = desc->aggregate_is_list;
+    s->d.is_list = desc->aggregate_kind == RRT_AGGREGATE_LIST ? 1u : 0u;
+    s->clean = desc->aggregate_kind == RRT_AGGREGATE_BVH_CLEAN;
     s->d.cam = desc->camera;
     s->res_x = desc->resolution_x;
     s->res_y = desc->resolution_y;
     s->samples = desc->samples;
     s->stack_depth = desc->bvh_depth ? desc->bvh_depth : 1;
     s->n_textures = desc->n_textures;
-    s->deep = desc->n_nodes > kDeepTreeNodes;
+    s->deep = desc->n_nodes > kDeepTreeNodes || s->clean;  // the clean mode's tie rule lives in the cooperative-leaf walk only
     // which code the scene needs (see F_* in rrt_device.hpp)
     for (uint32_t i = 0; i < desc->n_slots; ++i) {
         uint32_t kind = RRT_INFO_KIND(desc->slots[i].info);
@@ -733,7 +738,9 @@ int rrt_intersect_batch_device(rrt_scene* s, const float* d_o, const float* d_d,
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
     size_t lds = (size_t)kBlock * s->stack_depth * sizeof(uint32_t) + (size_t)(kBlock / 64) * (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave);
     hipStream_t st = (hipStream_t)stream;
-    if (aabb_mode == RRT_AABB_REFERENCE)
+    if (s->clean)
+        hipLaunchKernelGGL((k_intersect<kAabbClean, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
+    else if (aabb_mode == RRT_AABB_REFERENCE)
         if (s->deep) hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
         else hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE, false>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
     else
@@ -869,7 +876,10 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         else if ((need & ~kTextured) == 0) RRT_LAUNCH(MODE, kTextured, false);       \
         else RRT_LAUNCH(MODE, F_ALL, false);                                         \
     } while (0)
-        if (p->aabb_mode == RRT_AABB_REFERENCE) RRT_PICK(RRT_AABB_REFERENCE);
+        if (s->clean) {
+            if ((need & ~kPlain) == 0) RRT_LAUNCH(kAabbClean, kPlain, true);
+            else RRT_LAUNCH(kAabbClean, F_ALL, true);
+        } else if (p->aabb_mode == RRT_AABB_REFERENCE) RRT_PICK(RRT_AABB_REFERENCE);
         else RRT_PICK(RRT_AABB_TIGHT);
 #undef RRT_PICK
 #undef RRT_LAUNCH

@@ -14,6 +14,10 @@
 // as `<` does; and all of the reference's quirks are restated: every fold starts from the point box at the origin
 // (aggregate.rs:195, 423-428), and the suffix bounds never include the last shape (aggregate.rs:247-252).
 // Nodes are produced in breadth-first order and renumbered into the reference's depth-first pre-order on the host.
+//
+// `clean` builds the tree the algorithm was meant to build: bounds are those of the shapes alone (no origin box) and the
+// suffix bounds include the last shape.  That tree is NOT the reference's; it serves RRT_AGGREGATE_BVH_CLEAN, whose
+// traversal returns what the reference's List aggregate returns (aggregate.rs:142-165), at a fraction of the node visits.
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -102,13 +106,13 @@ __global__ void k_gather_bounds(const Box6* __restrict__ boxes, const uint32_t* 
 }
 
 // per segment: bounds (written to the node), leaf rules that need no sorting, cut axis
-__global__ void k_choose_axis(Seg* __restrict__ segs, uint32_t n_segs, const Bounds2* __restrict__ scanned, BfsNode* __restrict__ nodes) {
+__global__ void k_choose_axis(Seg* __restrict__ segs, uint32_t n_segs, const Bounds2* __restrict__ scanned, BfsNode* __restrict__ nodes, bool clean) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_segs) return;
     Seg sg = segs[s];
     const Bounds2 last = scanned[sg.lo + sg.n - 1];
-    const Box6 total = merge_boxes(origin_box(), last.box);  // the fold starts from the point box at the origin
-    const Box6 cen = merge_boxes(origin_box(), last.cen);
+    const Box6 total = clean ? last.box : merge_boxes(origin_box(), last.box);  // the reference's fold starts from the point box at the origin
+    const Box6 cen = clean ? last.cen : merge_boxes(origin_box(), last.cen);
     BfsNode nd;
     for (int c = 0; c < 3; ++c) {
         nd.bmin[c] = total.lo[c];
@@ -151,7 +155,7 @@ __global__ void k_make_keys(const Box6* __restrict__ boxes, const uint32_t* __re
 // bounds in sorted order, forwards; and backwards with every segment's last element left out (aggregate.rs:247-252)
 __global__ void k_gather_sorted(const Box6* __restrict__ boxes, const uint32_t* __restrict__ order, const uint32_t* __restrict__ pos_lo,
                                 const uint32_t* __restrict__ pos_seg, const Seg* __restrict__ segs, uint32_t n, Box6* __restrict__ fwd,
-                                Box6* __restrict__ rev, uint32_t* __restrict__ rev_key) {
+                                Box6* __restrict__ rev, uint32_t* __restrict__ rev_key, bool clean) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const Box6 b = boxes[order[i]];
@@ -160,7 +164,7 @@ __global__ void k_gather_sorted(const Box6* __restrict__ boxes, const uint32_t* 
     bool is_last = true;
     if (s != kNone) is_last = i == segs[s].lo + segs[s].n - 1;
     Box6 r = b;
-    if (is_last)  // neutral element: loses every comparison
+    if (is_last && !(clean && s != kNone))  // neutral element: loses every comparison
         for (int c = 0; c < 3; ++c) {
             r.lo[c] = __builtin_inff();
             r.hi[c] = -__builtin_inff();
@@ -171,7 +175,7 @@ __global__ void k_gather_sorted(const Box6* __restrict__ boxes, const uint32_t* 
 
 // cost of splitting after element i (aggregate.rs:254-265)
 __global__ void k_costs(const uint32_t* __restrict__ pos_seg, const Seg* __restrict__ segs, const BfsNode* __restrict__ nodes,
-                        const Box6* __restrict__ fwd_scan, const Box6* __restrict__ rev_scan, uint32_t n, Best* __restrict__ out) {
+                        const Box6* __restrict__ fwd_scan, const Box6* __restrict__ rev_scan, uint32_t n, Best* __restrict__ out, bool clean) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Best r;
@@ -189,9 +193,10 @@ __global__ void k_costs(const uint32_t* __restrict__ pos_seg, const Seg* __restr
                 total.hi[c] = nd.bmax[c];
             }
             const float total_area = box_area(total);
-            const Box6 prefix = merge_boxes(origin_box(), fwd_scan[i]);
-            // suffix[k+1] = shapes k+1 .. n-2 in order, then the origin box (which the loop starts from)
-            const Box6 suffix = merge_boxes(rev_scan[n - 1 - (i + 1)], origin_box());
+            // reference: suffix[k+1] = shapes k+1 .. n-2 in order, then the origin box (which the loop starts from); clean: the
+            // bounds of shapes 0..k and of shapes k+1..n-1, nothing else
+            const Box6 prefix = clean ? fwd_scan[i] : merge_boxes(origin_box(), fwd_scan[i]);
+            const Box6 suffix = clean ? rev_scan[n - 1 - (i + 1)] : merge_boxes(rev_scan[n - 1 - (i + 1)], origin_box());
             const float cost = 1.0f + ((box_area(prefix) / total_area) * (float)(k + 1)) + ((box_area(suffix) / total_area) * (float)(sg.n - (k + 1)));
             if (cost < FLT_MAX) {
                 r.cost = cost;
@@ -285,7 +290,7 @@ inline unsigned blocks_for(uint32_t n) { return (n + kThreads - 1) / kThreads; }
 
 }  // namespace
 
-int rrt_bvh_build_gpu(const float* boxes6, uint32_t n, std::vector<rrt_node>* out_nodes, std::vector<uint32_t>* out_order, uint32_t* out_depth) {
+int rrt_bvh_build_gpu(const float* boxes6, uint32_t n, bool clean, std::vector<rrt_node>* out_nodes, std::vector<uint32_t>* out_order, uint32_t* out_depth) {
     out_nodes->clear();
     out_order->clear();
     *out_depth = 0;
@@ -361,18 +366,18 @@ int rrt_bvh_build_gpu(const float* boxes6, uint32_t n, std::vector<rrt_node>* ou
         hipLaunchKernelGGL(k_gather_bounds, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_boxes, d_order, n, d_b2);
         need = temp_bytes;
         BVH_TRY(hipcub::DeviceScan::InclusiveScanByKey(d_temp, need, d_pos_lo, d_b2, d_b2_scan, Merge2Op(), (int)n));
-        hipLaunchKernelGGL(k_choose_axis, dim3(blocks_for(n_segs)), dim3(kThreads), 0, nullptr, d_segs, n_segs, d_b2_scan, d_nodes);
+        hipLaunchKernelGGL(k_choose_axis, dim3(blocks_for(n_segs)), dim3(kThreads), 0, nullptr, d_segs, n_segs, d_b2_scan, d_nodes, clean);
         hipLaunchKernelGGL(k_make_keys, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_boxes, d_order, d_pos_lo, d_pos_seg, d_segs, n, d_keys);
         need = temp_bytes;
         BVH_TRY(hipcub::DeviceRadixSort::SortPairs(d_temp, need, d_keys, d_keys_alt, d_order, d_order_alt, (int)n, 0, end_bit));
         std::swap(d_order, d_order_alt);
         hipLaunchKernelGGL(k_gather_sorted, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_boxes, d_order, d_pos_lo, d_pos_seg, d_segs, n, d_fwd, d_rev,
-                           d_rev_key);
+                           d_rev_key, clean);
         need = temp_bytes;
         BVH_TRY(hipcub::DeviceScan::InclusiveScanByKey(d_temp, need, d_pos_lo, d_fwd, d_fwd_scan, MergeOp(), (int)n));
         need = temp_bytes;
         BVH_TRY(hipcub::DeviceScan::InclusiveScanByKey(d_temp, need, d_rev_key, d_rev, d_rev_scan, MergeFlippedOp(), (int)n));
-        hipLaunchKernelGGL(k_costs, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_pos_seg, d_segs, d_nodes, d_fwd_scan, d_rev_scan, n, d_best);
+        hipLaunchKernelGGL(k_costs, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_pos_seg, d_segs, d_nodes, d_fwd_scan, d_rev_scan, n, d_best, clean);
         need = temp_bytes;
         BVH_TRY(hipcub::DeviceScan::InclusiveScanByKey(d_temp, need, d_pos_lo, d_best, d_best_scan, BestOp(), (int)n));
         hipLaunchKernelGGL(k_split, dim3(blocks_for(n_segs)), dim3(kThreads), 0, nullptr, d_segs, n_segs, d_best_scan, d_nodes, d_next, d_counters);

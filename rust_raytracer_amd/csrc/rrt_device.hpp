@@ -580,6 +580,11 @@ RRT_DEV bool pair_box_overlap(v2f_ x, v2f_ y, v2f_ z, f3 inv, f3 noi, float t_mi
     return t_near <= t_far;
 }
 
+// Third traversal mode, chosen by the library for trees built with RRT_AGGREGATE_BVH_CLEAN (never by the caller): nodes are
+// tested with the ordinary interval test on their primitive boxes alone, and equal distances go to the shape that comes
+// first in SCENE order - together exactly what the reference's List aggregate returns (aggregate.rs:142-165).
+constexpr int kAabbClean = 2;
+
 // ---- scene features a kernel variant is compiled for ------------------------------------------------------------------
 // The host picks the smallest variant that covers the scene, so scenes without media / image textures / bump maps do not
 // carry that code (registers, instruction cache) through the inner loop.
@@ -773,7 +778,7 @@ constexpr uint32_t kCoopBytesPerWave = 64 * 8 + 64 * 16;
 #endif
 constexpr uint32_t kCoopLanes = RRT_COOP_LANES;  // paused lanes that trigger a cooperative leaf phase
 
-template <uint32_t FEAT>
+template <uint32_t FEAT, bool CLEAN>
 RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng& key, uint32_t depth, bool pending, uint32_t first_pair, uint32_t n_pairs,
                          Hit& h, unsigned char* coop) {
     const uint32_t lane = threadIdx.x & 63u;
@@ -787,7 +792,12 @@ RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng&
         if (lane >= off) incl += up;
     }
     const uint32_t total = (uint32_t)__shfl((int)incl, 63);
-    best[lane] = ((unsigned long long)ord_bits(h.t) << 32);  // position 0: what the owner already holds wins ties
+    // Ties: in the reference's tree the leaf visited first wins, so what the owner already holds gets position 0; in a clean
+    // tree the shape that is first in scene order wins wherever it sits, so positions are shape numbers throughout.
+    uint32_t held = 0u;
+    if (CLEAN && h.slot >= 0) held = __float_as_uint(sc.c_slots()[3 * h.slot].w) + 1u;
+    const unsigned long long init = ((unsigned long long)ord_bits(h.t) << 32) | held;
+    best[lane] = init;
     __threadfence_block();
     const cv4p cpairs = sc.c_pairs();
     for (uint32_t base = 0; base < total; base += 64u) {
@@ -817,13 +827,20 @@ RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng&
         Hit hh;
         hh.slot = -1;
         hh.t = o_t;
+        if (CLEAN && __shfl(h.slot, owner) >= 0) hh.t = ord_float(ord_bits(o_t) + 1u);  // an equal distance may still win on shape order
         hh.u = hh.v = hh.det = 0.0f;
         unsigned long long mykey = ~0ull;
         if (have) {
             const uint32_t k = item - (o_incl - o_n);  // position of the pair in its leaf
-            test_pair<FEAT>(sc, cpairs + kPairQuads * (o_first + k), ro, t_min, okey, odepth, hh);
+            const cv4p rec = cpairs + kPairQuads * (o_first + k);
+            test_pair<FEAT>(sc, rec, ro, t_min, okey, odepth, hh);
             if (hh.slot >= 0) {
-                mykey = ((unsigned long long)ord_bits(hh.t) << 32) | (unsigned long long)((uint32_t)hh.slot + 1u);
+                uint32_t pos = (uint32_t)hh.slot;
+                if (CLEAN) {
+                    const v4f q5 = rec[5];  // (slot A, slot B, shape A, shape B)
+                    pos = __float_as_uint(pos == __float_as_uint(q5.x) ? q5.z : q5.w);
+                }
+                mykey = ((unsigned long long)ord_bits(hh.t) << 32) | (unsigned long long)(pos + 1u);
                 atomicMin(&best[owner], mykey);
             }
         }
@@ -831,7 +848,7 @@ RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng&
         if (hh.slot >= 0 && best[owner] == mykey) payload[owner] = v4f{__uint_as_float((uint32_t)hh.slot), hh.det, hh.u, hh.v};
         __threadfence_block();
     }
-    if (pending && (uint32_t)best[lane] != 0u) {
+    if (pending && best[lane] != init) {
         const v4f w = payload[lane];
         h.t = ord_float((uint32_t)(best[lane] >> 32));
         h.slot = (int)__float_as_uint(w.x);
@@ -866,7 +883,10 @@ RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float 
             const v4f n1 = cnodes[4 * cur + 1];
             bool inside;
             if (sc.is_list) inside = true;
-            else if (AABB_MODE == RRT_AABB_TIGHT) {
+            else if (AABB_MODE == kAabbClean) {
+                const v4f b0 = cnodes[4 * cur + 2], b1 = cnodes[4 * cur + 3];
+                inside = box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t);
+            } else if (AABB_MODE == RRT_AABB_TIGHT) {
                 const v4f b0 = cnodes[4 * cur + 2], b1 = cnodes[4 * cur + 3];
                 inside = box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
             } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
@@ -875,7 +895,7 @@ RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float 
                 // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
                 const float dax = b == 0u ? r.d.x : (b == 1u ? r.d.y : r.d.z);
                 const uint32_t left = cur + 1u, right = a;
-                const bool left_first = dax < 0.0f;
+                const bool left_first = AABB_MODE == kAabbClean ? !(dax < 0.0f) : dax < 0.0f;  // clean: the nearer child first
                 stack[sp * stride] = left_first ? right : left;
                 ++sp;
                 cur = left_first ? left : right;
@@ -900,7 +920,7 @@ RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float 
 #ifdef RRT_PHASE_PROFILE
             if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_leaf_steps;
 #endif
-            coop_leaves<FEAT>(sc, r, t_min, key, depth, pending, first_pair, n_pairs, h, coop);
+            coop_leaves<FEAT, AABB_MODE == kAabbClean>(sc, r, t_min, key, depth, pending, first_pair, n_pairs, h, coop);
             if (pending) {
                 pending = false;
                 if (sp != 0) {

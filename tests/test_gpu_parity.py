@@ -212,6 +212,33 @@ def test_one_big_leaf_with_ties_bit_exact(gpu, aggregate, n):
         assert st["rays"] == int(st_ref[0])
 
 
+@pytest.mark.parametrize("case", ["terrain", "slats", "spheres"])
+def test_clean_bvh_returns_what_the_list_aggregate_returns(gpu, case):
+    """RRT_AGGREGATE_BVH_CLEAN (a tree of its own, built on the device) against the oracle's LIST aggregate: nearest hit, equal
+    distances to the shape that is first in scene order, bit-exact distances; rendered frames bit-exact too."""
+    if case == "terrain":
+        d = synth.terrain_desc(60, seed=3, width=40, height=40, samples=2)
+    elif case == "slats":
+        d = synth.slats_desc(n=40, aggregate=0)  # shapes duplicated in place: exact ties
+    else:
+        d = synth.spheres_desc(media=6)
+    o = orc.OracleScene(dict(d, aggregate=0))
+    g = rrt.Scene(synth.host_scene(d, "BVH_CLEAN"))
+    W, H, spp = d["logistics"]["resolution_x"], d["logistics"]["resolution_y"], d["logistics"]["samples"]
+    ro, rd = raygen.ray_batch(o, W, H, n_random=5000, seed=13)
+    for t_min in (0.001, -1.5):
+        p_ref, t_ref = o.intersect(ro, rd, t_min=t_min)
+        assert (p_ref >= 0).sum() > 2000
+        p, t = g.hit(ro, rd, t_min=t_min)
+        assert np.array_equal(p, p_ref), "primitive ids differ: %d rays" % (p != p_ref).sum()
+        assert np.array_equal(bits(t), bits(t_ref))
+    ref, st_ref = o.render(W, H, spp, seed=6, bg=rrt.BG_SKY)
+    img, st = g.render(seed=6, background=rrt.BG_SKY)
+    same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+    assert same.all(), "%d of %d values differ" % ((~same).sum(), same.size)
+    assert st["rays"] == int(st_ref[0])
+
+
 def _same_records(a, b):
     return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
 

@@ -186,7 +186,7 @@ def test_builder_api_and_list_aggregate():
     hs.set_logistics(16, 16, 2)
     hs.finalize("List")
     d = hs.desc
-    assert d.aggregate_is_list == 1 and d.n_nodes == 1 and d.n_slots == 3 and d.n_lights == 2
+    assert d.aggregate_kind == 0 and d.n_nodes == 1 and d.n_slots == 3 and d.n_lights == 2
     assert list(hs.slots()["prim"]) == [0, 1, 2]  # scene order
     with pytest.raises(rrt.RrtError):
         hs.add_material(0, 99)

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""GPU-box timing of the synthetic displaced-grid mesh: python tools/perf_mesh.py N W H SPP  (2*N*N triangles)."""
+"""GPU-box timing of the synthetic displaced-grid mesh: python tools/perf_mesh.py N W H SPP [tight] [host|clean]  (2*N*N triangles;
+"host" builds the tree on the host instead of the GPU)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -10,11 +11,13 @@ import synth
 n, W, H, spp = (int(a) for a in sys.argv[1:5])
 t0 = time.time()
 d = synth.terrain_desc(n, width=W, height=H, samples=spp)
-hs = synth.host_scene(d)
+torch.zeros(1, device="cuda")
+t0 = time.time()
+hs = synth.host_scene(d, "BVH" if "host" in sys.argv else ("BVH_CLEAN" if "clean" in sys.argv else "BVH_GPU"))
 t1 = time.time()
 sc = rrt.Scene(hs)
 t2 = time.time()
-print("triangles %d nodes %d depth %d: host build %.2f s, upload %.2f s" % (2 * n * n, hs.desc.n_nodes, hs.desc.bvh_depth, t1 - t0, t2 - t1), flush=True)
+print("triangles %d nodes %d depth %d: scene + tree build %.2f s, upload %.2f s" % (2 * n * n, hs.desc.n_nodes, hs.desc.bvh_depth, t1 - t0, t2 - t1), flush=True)
 img = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
 cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
 st = torch.cuda.current_stream()
