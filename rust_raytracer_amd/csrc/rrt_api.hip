@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <string>
@@ -34,6 +35,7 @@ struct TraceArgs {
     uint32_t tile_count, tile_index, tiles_x, n_tiles;  // 32x32-pixel tiles (multi-GPU sharding unit)
     uint32_t n_t8;                                       // 8x8-pixel wave tiles owned by this call
     uint32_t stack_depth;                                // LDS stack entries per lane (the cooperative-leaf area follows the stack)
+    uint32_t coop_lanes, shade_lanes;                    // k_trace_stream: paused / finished lanes that trigger a leaf / shading phase
 };
 
 // ---- the trace kernel -------------------------------------------------------------------------------------
@@ -169,6 +171,133 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
 #ifdef RRT_PHASE_PROFILE
     if (counters && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&counters[2 + i], pc[i]);
+#endif
+    if (counters) {
+        for (int off = 32; off > 0; off >>= 1) {
+            rays += __shfl_down(rays, off);
+            paths += __shfl_down(paths, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[0], rays);
+            atomicAdd(&counters[1], paths);
+        }
+    }
+}
+
+// ---- the trace kernel for deep trees ------------------------------------------------------------------------
+// Same work and same results as k_trace<.., DEEP = true>, other schedule.  On a large mesh the rays of a wave need very
+// different numbers of node visits (a mean of 300 against 2 000 for the slowest lane of a wave on a 10 M-triangle mesh), and a
+// loop that runs query - shade - query in step leaves most lanes idle most of the time.  Here every lane is a small state
+// machine - FRESH (has a pool sample, no ray yet), WALK (visiting nodes), LEAF (paused at a leaf), READY (query finished) -
+// and the wave's loop does, each turn: one node for the WALK lanes; a cooperative leaf phase when enough lanes are paused;
+// a shading phase (shade, store, draw the next sample, make the camera ray) when enough lanes are READY or FRESH.  A lane
+// that finishes its query early is shaded and sent walking again while its neighbours are still in their queries.
+template <int AABB_MODE, uint32_t FEAT>
+__global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stream(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t chunk = blockIdx.x / ta.n_t8, j = blockIdx.x % ta.n_t8;
+    const uint32_t tile32 = ta.tile_index + (j >> 4) * ta.tile_count;
+    const uint32_t x0 = (tile32 % ta.tiles_x) * 32u + ((j & 3u) << 3);
+    const uint32_t y0 = (tile32 / ta.tiles_x) * 32u + (((j >> 2) & 3u) << 3);
+    const uint32_t s0 = chunk * kChunk;
+    const uint32_t ns = ta.n_samples - s0 < kChunk ? ta.n_samples - s0 : kChunk;
+    const uint32_t pool = ns * 64u;
+    uint32_t* stack = lds_stack + lane;
+    unsigned char* coop = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
+    enum : uint32_t { DEAD = 0, FRESH = 1, WALK = 2, LEAF = 3, READY = 4 };
+
+    uint32_t next = 64u;  // next undrawn pool index (wave-uniform)
+    uint32_t idx = lane;
+    uint32_t st = idx < pool ? FRESH : DEAD;
+    unsigned long long rays = 0, paths = 0;
+    uint32_t px = 0, py = 0, smp = 0, depth = 0;
+    Ray r;
+    f3 thr;
+    Rng g;
+    r.o = r.d = thr = mk3(0.0f, 0.0f, 0.0f);
+    g.s0 = g.s1 = 0;
+    Walk w;
+    walk_begin(sc, w, false, r, RRT_T_MAX);
+#ifdef RRT_PHASE_PROFILE
+    unsigned long long prof_nodes = 0, prof_pairs = 0, prof_steps = 0, prof_leaf_steps = 0;
+#endif
+    for (;;) {
+        const unsigned long long walking = RRT_BALLOT(st == WALK), paused = RRT_BALLOT(st == LEAF), waiting = RRT_BALLOT(st == READY || st == FRESH);
+        if ((walking | paused | waiting) == 0ull) break;
+        if (waiting != 0ull && ((uint32_t)__popcll(waiting) >= ta.shade_lanes || (walking | paused) == 0ull)) {
+            bool done = false;  // this lane needs a new sample
+            bool launch = false;  // this lane has a new ray to trace
+            if (st == READY) {
+                ++rays;
+                f3 radiance;
+                done = shade<FEAT>(sc, w.h, r, thr, g, depth, ta.max_depth, ta.bg, &radiance);
+                if (done) {
+                    f3 c = thr * radiance;
+                    float* q = slab + (((size_t)smp * ta.H + py) * ta.W + px) * 3;
+                    q[0] = c.x;
+                    q[1] = c.y;
+                    q[2] = c.z;
+                } else {
+                    ++depth;
+                    launch = true;
+                }
+            } else if (st == FRESH) {
+                px = x0 + (idx & 7u);
+                py = y0 + ((idx >> 3) & 7u);
+                smp = s0 + (idx >> 6);
+                if (px < ta.W && py < ta.H) {
+                    g = rng_seed(ta.seed, py * ta.W + px, ta.first_sample + smp);
+                    r = camera_ray(sc.cam, px, py, ta.W, ta.H, g);
+                    thr = mk3(1.0f, 1.0f, 1.0f);
+                    depth = 0;
+                    ++paths;
+                    launch = true;
+                } else {
+                    done = true;  // a pixel beyond the frame's edge: nothing to trace
+                }
+            }
+            if (launch) {
+                walk_begin(sc, w, true, r, RRT_T_MAX);
+                st = w.running ? WALK : READY;  // an empty scene answers at once
+            }
+            const unsigned long long finished = RRT_BALLOT(done);
+            if (done) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(finished >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)finished, 0u));
+                idx = next + rank;
+                st = idx < pool ? FRESH : DEAD;
+            }
+            next += (uint32_t)__popcll(finished);
+            continue;
+        }
+        if (st == WALK) {
+            RRT_COUNT(prof_nodes, 1);
+            walk_step<AABB_MODE>(sc, w, r, RRT_T_MIN, stack, kTraceBlock);
+            if (w.pending) {
+                st = LEAF;
+                RRT_COUNT(prof_pairs, w.n_pairs);
+            } else if (!w.running) st = READY;
+        }
+#ifdef RRT_PHASE_PROFILE
+        if (lane == 0) ++prof_steps;
+#endif
+        const unsigned long long at_leaf = RRT_BALLOT(st == LEAF);
+        if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= ta.coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
+#ifdef RRT_PHASE_PROFILE
+            if (lane == 0) ++prof_leaf_steps;
+#endif
+            coop_leaves<FEAT, AABB_MODE == kAabbClean>(sc, r, RRT_T_MIN, g, depth, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
+            if (st == LEAF) {
+                walk_resume(w, stack, kTraceBlock);
+                st = w.running ? WALK : READY;
+            }
+        }
+    }
+#ifdef RRT_PHASE_PROFILE
+    atomicAdd(&g_prof[0], prof_nodes);
+    atomicAdd(&g_prof[1], prof_pairs);
+    atomicAdd(&g_prof[2], prof_steps);
+    atomicAdd(&g_prof[3], prof_leaf_steps);
 #endif
     if (counters) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -841,6 +970,8 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
     }
     const size_t lds = (size_t)kTraceBlock * s->stack_depth * sizeof(uint32_t) + (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave + kHarvestBytesPerWave);
     ta.stack_depth = s->stack_depth;
+    ta.coop_lanes = 16;   // measured on a 500 000-triangle mesh, 1024x1024 @ 64 spp: 8/16 -> 398 ms, 16/16 -> 344 ms, 24/12 -> 340 ms,
+    ta.shade_lanes = 16;  // 32/32 -> 440 ms, 48/48 -> 728 ms (paused / finished lanes that trigger a leaf / shading phase)
     hipStream_t st = (hipStream_t)stream;
     // compiled variants: plain (triangles + spheres, constant textures), textured (+ textures, bump maps), full (+ media)
     constexpr uint32_t kPlain = F_SPHERE, kTextured = F_SPHERE | F_TEX | F_BUMP;
@@ -864,11 +995,12 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         if (items > 0x7fffffffull) return rrt_set_error(RRT_ERR_LIMIT, "rrt_render: too many work items in one pass");
         const dim3 grid((unsigned)items);
 #define RRT_LAUNCH(MODE, FEAT, DEEP) hipLaunchKernelGGL((k_trace<MODE, FEAT, DEEP>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt)
+#define RRT_LAUNCH_STREAM(MODE, FEAT) hipLaunchKernelGGL((k_trace_stream<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt)
 #define RRT_PICK(MODE)                                                               \
     do {                                                                             \
         if (s->deep) {                                                               \
-            if ((need & ~kPlain) == 0) RRT_LAUNCH(MODE, kPlain, true);               \
-            else RRT_LAUNCH(MODE, F_ALL, true);                                      \
+            if ((need & ~kPlain) == 0) RRT_LAUNCH_STREAM(MODE, kPlain);              \
+            else RRT_LAUNCH_STREAM(MODE, F_ALL);                                     \
         } else if ((need & ~kPlain) == 0) {                                          \
             if (s->harvest) hipLaunchKernelGGL((k_trace<MODE, kPlain, false, true>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt); \
             else RRT_LAUNCH(MODE, kPlain, false);                                    \
@@ -877,12 +1009,13 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         else RRT_LAUNCH(MODE, F_ALL, false);                                         \
     } while (0)
         if (s->clean) {
-            if ((need & ~kPlain) == 0) RRT_LAUNCH(kAabbClean, kPlain, true);
-            else RRT_LAUNCH(kAabbClean, F_ALL, true);
+            if ((need & ~kPlain) == 0) RRT_LAUNCH_STREAM(kAabbClean, kPlain);
+            else RRT_LAUNCH_STREAM(kAabbClean, F_ALL);
         } else if (p->aabb_mode == RRT_AABB_REFERENCE) RRT_PICK(RRT_AABB_REFERENCE);
         else RRT_PICK(RRT_AABB_TIGHT);
 #undef RRT_PICK
 #undef RRT_LAUNCH
+#undef RRT_LAUNCH_STREAM
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((frame_floats + 255) / 256)), dim3(256), 0, st, s->slab, ta.n_samples, frame_floats, ta.W,

@@ -858,61 +858,90 @@ RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng&
     }
 }
 
+// One lane's walk through a deep tree, kept between steps so that callers can interleave the lanes of a wave freely.
+struct Walk {
+    uint32_t sp, cur;
+    bool running;  // has a node to visit
+    bool pending;  // stands at a leaf (first_pair, n_pairs) that the next cooperative phase tests
+    uint32_t first_pair, n_pairs;
+    f3 inv;
+    Hit h;
+};
+RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, float t_max) {
+    w.h.slot = -1;
+    w.h.t = t_max;
+    w.h.u = w.h.v = w.h.det = 0.0f;
+    w.sp = 0;
+    w.cur = 0;
+    w.pending = false;
+    w.first_pair = w.n_pairs = 0;
+    w.running = active && sc.n_nodes != 0;
+    w.inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+}
+// Visits one node (BVH::hit, aggregate.rs:343-395): an inner node that passes its test pushes one child and descends into the
+// other, a leaf that passes pauses the walk, anything else pops.
+template <int AABB_MODE>
+RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, uint32_t* stack, uint32_t stride) {
+    const cv4p cnodes = sc.c_nodes();
+    const v4f n0 = cnodes[4 * w.cur];
+    const v4f n1 = cnodes[4 * w.cur + 1];
+    bool inside;
+    if (sc.is_list) inside = true;
+    else if (AABB_MODE == kAabbClean) {
+        const v4f b0 = cnodes[4 * w.cur + 2], b1 = cnodes[4 * w.cur + 3];
+        inside = box_overlap(xyz(b0), xyz(b1), r.o, w.inv, t_min, w.h.t);
+    } else if (AABB_MODE == RRT_AABB_TIGHT) {
+        const v4f b0 = cnodes[4 * w.cur + 2], b1 = cnodes[4 * w.cur + 3];
+        inside = box_overlap(xyz(b0), xyz(b1), r.o, w.inv, t_min, w.h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, w.inv, t_min, w.h.t);
+    } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, w.inv, t_min, w.h.t);
+    const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
+    if (inside && !(b & RRT_LEAF_FLAG)) {
+        // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
+        const float dax = b == 0u ? r.d.x : (b == 1u ? r.d.y : r.d.z);
+        const uint32_t left = w.cur + 1u, right = a;
+        const bool left_first = AABB_MODE == kAabbClean ? !(dax < 0.0f) : dax < 0.0f;  // clean: the nearer child first
+        stack[w.sp * stride] = left_first ? right : left;
+        ++w.sp;
+        w.cur = left_first ? left : right;
+    } else if (inside) {
+        w.pending = true;  // the leaf is tested in the next cooperative phase; the walk resumes after it
+        w.running = false;
+        w.first_pair = a;
+        w.n_pairs = b & ~RRT_LEAF_FLAG;
+    } else if (w.sp == 0) {
+        w.running = false;
+    } else {
+        --w.sp;
+        w.cur = stack[w.sp * stride];
+    }
+}
+// After the cooperative phase that tested this lane's leaf.
+RRT_DEV void walk_resume(Walk& w, uint32_t* stack, uint32_t stride) {
+    w.pending = false;
+    if (w.sp != 0) {
+        --w.sp;
+        w.cur = stack[w.sp * stride];
+        w.running = true;
+    }
+}
+
 template <int AABB_MODE, uint32_t FEAT>
 RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack,
                              uint32_t stride, unsigned char* coop) {
     // Must be called by all 64 lanes of the wave (the cooperative phase addresses lanes by number); lanes without a ray
     // pass active = false and only lend a hand.
-    Hit h;
-    h.slot = -1;
-    h.t = t_max;
-    h.u = h.v = h.det = 0.0f;
-    if (sc.n_nodes == 0) return h;
-    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
-    const cv4p cnodes = sc.c_nodes();
-    uint32_t sp = 0, cur = 0;
-    bool running = active, pending = false;
-    uint32_t first_pair = 0, n_pairs = 0;
+    Walk w;
+    walk_begin(sc, w, active, r, t_max);
 #ifdef RRT_PHASE_PROFILE
     unsigned long long prof_nodes = 0, prof_pairs = 0, prof_steps = 0, prof_leaf_steps = 0;
 #endif
     for (;;) {
-        if (running) {
+        if (w.running) {
             RRT_COUNT(prof_nodes, 1);
-            const v4f n0 = cnodes[4 * cur];
-            const v4f n1 = cnodes[4 * cur + 1];
-            bool inside;
-            if (sc.is_list) inside = true;
-            else if (AABB_MODE == kAabbClean) {
-                const v4f b0 = cnodes[4 * cur + 2], b1 = cnodes[4 * cur + 3];
-                inside = box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t);
-            } else if (AABB_MODE == RRT_AABB_TIGHT) {
-                const v4f b0 = cnodes[4 * cur + 2], b1 = cnodes[4 * cur + 3];
-                inside = box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
-            } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
-            const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
-            if (inside && !(b & RRT_LEAF_FLAG)) {
-                // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
-                const float dax = b == 0u ? r.d.x : (b == 1u ? r.d.y : r.d.z);
-                const uint32_t left = cur + 1u, right = a;
-                const bool left_first = AABB_MODE == kAabbClean ? !(dax < 0.0f) : dax < 0.0f;  // clean: the nearer child first
-                stack[sp * stride] = left_first ? right : left;
-                ++sp;
-                cur = left_first ? left : right;
-            } else if (inside) {
-                pending = true;  // the leaf is tested in the next cooperative phase; the walk resumes after it
-                running = false;
-                first_pair = a;
-                n_pairs = b & ~RRT_LEAF_FLAG;
-                RRT_COUNT(prof_pairs, n_pairs);
-            } else if (sp == 0) {
-                running = false;
-            } else {
-                --sp;
-                cur = stack[sp * stride];
-            }
+            walk_step<AABB_MODE>(sc, w, r, t_min, stack, stride);
+            if (w.pending) RRT_COUNT(prof_pairs, w.n_pairs);
         }
-        const unsigned long long waiting = __ballot(pending), walking = __ballot(running);
+        const unsigned long long waiting = RRT_BALLOT(w.pending), walking = RRT_BALLOT(w.running);
 #ifdef RRT_PHASE_PROFILE
         if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_steps;
 #endif
@@ -920,15 +949,8 @@ RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float 
 #ifdef RRT_PHASE_PROFILE
             if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_leaf_steps;
 #endif
-            coop_leaves<FEAT, AABB_MODE == kAabbClean>(sc, r, t_min, key, depth, pending, first_pair, n_pairs, h, coop);
-            if (pending) {
-                pending = false;
-                if (sp != 0) {
-                    --sp;
-                    cur = stack[sp * stride];
-                    running = true;
-                }
-            }
+            coop_leaves<FEAT, AABB_MODE == kAabbClean>(sc, r, t_min, key, depth, w.pending, w.first_pair, w.n_pairs, w.h, coop);
+            if (w.pending) walk_resume(w, stack, stride);
         } else if (waiting == 0ull && walking == 0ull) {
             break;
         }
@@ -939,7 +961,7 @@ RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float 
     atomicAdd(&g_prof[2], prof_steps);
     atomicAdd(&g_prof[3], prof_leaf_steps);
 #endif
-    return h;
+    return w.h;
 }
 
 // Recomputes (u, v, det) the way Triangle::get_hit_properties does (shape.rs:384-400) for callers without a Hit.
