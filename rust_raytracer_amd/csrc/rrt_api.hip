@@ -38,7 +38,7 @@ struct TraceArgs {
     uint32_t coop_lanes, shade_lanes;                    // k_trace_stream: paused / finished lanes that trigger a leaf / shading phase
 };
 
-// ---- the trace kernel -------------------------------------------------------------------------------------
+// ---- the trace kernel for shallow trees (at most kDeepTreeNodes nodes; deep trees: k_trace_stream) ------------------------
 // ≙ main.rs:200-257 (thread_work) + aggregate.rs:16-105 (trace), for one pass of `n_samples` samples per pixel.
 //
 // A wave owns an 8x8-pixel tile and a chunk of up to 64 consecutive samples of each of its pixels: a pool of
@@ -51,7 +51,7 @@ struct TraceArgs {
 #ifndef RRT_TRACE_MIN_WAVES
 #define RRT_TRACE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
-template <int AABB_MODE, uint32_t FEAT, bool DEEP, bool HARVEST = false>
+template <int AABB_MODE, uint32_t FEAT, bool HARVEST = false>
 __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t lane = threadIdx.x;
@@ -122,9 +122,8 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
             Hit hit;
             unsigned char* area = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
             float harvest[kHarvestLights];
-            if (DEEP) hit = closest_hit_deep<AABB_MODE, FEAT>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area);
-            else hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
-            if (!DEEP && (RRT_DUP & 1)) {
+            hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
+            if (RRT_DUP & 1) {
                 Ray r2 = r;
                 RRT_OPAQUE(r2.o.x);
                 float harvest2[kHarvestLights];
@@ -185,7 +184,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
 }
 
 // ---- the trace kernel for deep trees ------------------------------------------------------------------------
-// Same work and same results as k_trace<.., DEEP = true>, other schedule.  On a large mesh the rays of a wave need very
+// Same work and same results as k_trace, other schedule.  On a large mesh the rays of a wave need very
 // different numbers of node visits (a mean of 300 against 2 000 for the slowest lane of a wave on a 10 M-triangle mesh), and a
 // loop that runs query - shade - query in step leaves most lanes idle most of the time.  Here every lane is a small state
 // machine - FRESH (has a pool sample, no ray yet), WALK (visiting nodes), LEAF (paused at a leaf), READY (query finished) -
@@ -760,12 +759,23 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             n.b = RRT_LEAF_FLAG | ((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair);
         }
         const std::vector<float> tb = tight_boxes(desc);
-        std::vector<float> rec((size_t)dn.size() * 16);  // node (32 bytes) + primitive box (32 bytes) per 64-byte record
-        for (size_t i = 0; i < dn.size(); ++i) {
-            std::memcpy(&rec[i * 16], &dn[i], 32);
-            std::memcpy(&rec[i * 16 + 8], &tb[i * 8], 32);
+        if (clean) {  // 32-byte nodes: the primitive box with the links in the fourth lanes
+            std::vector<float> rec((size_t)dn.size() * 8);
+            for (size_t i = 0; i < dn.size(); ++i) {
+                std::memcpy(&rec[i * 8], &tb[i * 8], 12);
+                std::memcpy(&rec[i * 8 + 3], &dn[i].a, 4);
+                std::memcpy(&rec[i * 8 + 4], &tb[i * 8 + 4], 12);
+                std::memcpy(&rec[i * 8 + 7], &dn[i].b, 4);
+            }
+            UP(nodes, (const float4*)rec.data(), rec.size() / 4);
+        } else {
+            std::vector<float> rec((size_t)dn.size() * 16);  // node (32 bytes) + primitive box (32 bytes) per 64-byte record
+            for (size_t i = 0; i < dn.size(); ++i) {
+                std::memcpy(&rec[i * 16], &dn[i], 32);
+                std::memcpy(&rec[i * 16 + 8], &tb[i * 8], 32);
+            }
+            UP(nodes, (const float4*)rec.data(), rec.size() / 4);
         }
-        UP(nodes, (const float4*)rec.data(), rec.size() / 4);
         UP(pairs, (const float4*)pairs.data(), pairs.size() / 4);
     }
     UP(slots, (const float4*)desc->slots, (size_t)desc->n_slots * 3);
@@ -994,7 +1004,7 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         const uint64_t items = (uint64_t)((ta.n_samples + kChunk - 1) / kChunk) * ta.n_t8;
         if (items > 0x7fffffffull) return rrt_set_error(RRT_ERR_LIMIT, "rrt_render: too many work items in one pass");
         const dim3 grid((unsigned)items);
-#define RRT_LAUNCH(MODE, FEAT, DEEP) hipLaunchKernelGGL((k_trace<MODE, FEAT, DEEP>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt)
+#define RRT_LAUNCH(MODE, FEAT) hipLaunchKernelGGL((k_trace<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt)
 #define RRT_LAUNCH_STREAM(MODE, FEAT) hipLaunchKernelGGL((k_trace_stream<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt)
 #define RRT_PICK(MODE)                                                               \
     do {                                                                             \
@@ -1002,11 +1012,11 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
             if ((need & ~kPlain) == 0) RRT_LAUNCH_STREAM(MODE, kPlain);              \
             else RRT_LAUNCH_STREAM(MODE, F_ALL);                                     \
         } else if ((need & ~kPlain) == 0) {                                          \
-            if (s->harvest) hipLaunchKernelGGL((k_trace<MODE, kPlain, false, true>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt); \
-            else RRT_LAUNCH(MODE, kPlain, false);                                    \
+            if (s->harvest) hipLaunchKernelGGL((k_trace<MODE, kPlain, true>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt); \
+            else RRT_LAUNCH(MODE, kPlain);                                           \
         }                                                                            \
-        else if ((need & ~kTextured) == 0) RRT_LAUNCH(MODE, kTextured, false);       \
-        else RRT_LAUNCH(MODE, F_ALL, false);                                         \
+        else if ((need & ~kTextured) == 0) RRT_LAUNCH(MODE, kTextured);              \
+        else RRT_LAUNCH(MODE, F_ALL);                                                \
     } while (0)
         if (s->clean) {
             if ((need & ~kPlain) == 0) RRT_LAUNCH_STREAM(kAabbClean, kPlain);

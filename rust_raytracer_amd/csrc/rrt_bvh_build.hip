@@ -106,7 +106,8 @@ __global__ void k_gather_bounds(const Box6* __restrict__ boxes, const uint32_t* 
 }
 
 // per segment: bounds (written to the node), leaf rules that need no sorting, cut axis
-__global__ void k_choose_axis(Seg* __restrict__ segs, uint32_t n_segs, const Bounds2* __restrict__ scanned, BfsNode* __restrict__ nodes, bool clean) {
+__global__ void k_choose_axis(Seg* __restrict__ segs, uint32_t n_segs, const Bounds2* __restrict__ scanned, BfsNode* __restrict__ nodes, bool clean,
+                              uint32_t leaf_max) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= n_segs) return;
     Seg sg = segs[s];
@@ -122,7 +123,7 @@ __global__ void k_choose_axis(Seg* __restrict__ segs, uint32_t n_segs, const Bou
     nd.n = sg.n;
     nd.left = nd.right = kNone;
     uint32_t axis = 3;
-    if (sg.n > 2) {  // aggregate.rs:204
+    if (sg.n > leaf_max) {  // aggregate.rs:204
         const float dx = cen.hi[0] - cen.lo[0], dy = cen.hi[1] - cen.lo[1], dz = cen.hi[2] - cen.lo[2];
         axis = (dx > dy && dx > dz) ? 0u : (dy > dz ? 1u : 2u);  // aggregate.rs:452-461
         if (cen.hi[axis] == cen.lo[axis]) axis = 3;              // aggregate.rs:225
@@ -344,6 +345,7 @@ int rrt_bvh_build_gpu(const float* boxes6, uint32_t n, bool clean, std::vector<r
     void* d_temp = nullptr;
     BVH_TRY(mem.get((unsigned char**)&d_temp, temp_bytes));
 
+    const uint32_t leaf_max = 2;  // aggregate.rs:204 (clean trees: leaves of up to 4 or 8 shapes were measured no faster)
     // level 0: one segment holding every shape in scene order
     hipLaunchKernelGGL(k_iota, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_order, n, kNone);
     hipLaunchKernelGGL(k_iota, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_pos_lo, n, 0u);
@@ -366,7 +368,7 @@ int rrt_bvh_build_gpu(const float* boxes6, uint32_t n, bool clean, std::vector<r
         hipLaunchKernelGGL(k_gather_bounds, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_boxes, d_order, n, d_b2);
         need = temp_bytes;
         BVH_TRY(hipcub::DeviceScan::InclusiveScanByKey(d_temp, need, d_pos_lo, d_b2, d_b2_scan, Merge2Op(), (int)n));
-        hipLaunchKernelGGL(k_choose_axis, dim3(blocks_for(n_segs)), dim3(kThreads), 0, nullptr, d_segs, n_segs, d_b2_scan, d_nodes, clean);
+        hipLaunchKernelGGL(k_choose_axis, dim3(blocks_for(n_segs)), dim3(kThreads), 0, nullptr, d_segs, n_segs, d_b2_scan, d_nodes, clean, leaf_max);
         hipLaunchKernelGGL(k_make_keys, dim3(blocks_for(n)), dim3(kThreads), 0, nullptr, d_boxes, d_order, d_pos_lo, d_pos_seg, d_segs, n, d_keys);
         need = temp_bytes;
         BVH_TRY(hipcub::DeviceRadixSort::SortPairs(d_temp, need, d_keys, d_keys_alt, d_order, d_order_alt, (int)n, 0, end_bit));

@@ -204,7 +204,8 @@ RRT_DEV f3 xyz(v4f q) { return f3{q.x, q.y, q.z}; }
 // ---- device view of the scene ----------------------------------------------------------------------
 struct DScene {
     const float4* nodes;      // 4 x float4 per node: the rrt_node (a leaf's `a` holds its first PAIR index), then the padded
-                              // box its primitives occupy (lo, hi), which the TIGHT traversal tests as well: one 64-byte line
+                              // box its primitives occupy (lo, hi), which the TIGHT traversal tests as well: one 64-byte line.
+                              // Clean trees: 2 x float4 per node, (box lo, a), (box hi, b) with the primitive box only
     const float4* pairs;      // kPairQuads x float4 per two consecutive primitives of a leaf (see triangle_pair_eval)
     const float4* slots;      // 3 x float4 per rrt_slot
     const float4* tri_shade;  // 4 x float4 per rrt_tri_shade
@@ -883,13 +884,13 @@ RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, fl
 template <int AABB_MODE>
 RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, uint32_t* stack, uint32_t stride) {
     const cv4p cnodes = sc.c_nodes();
-    const v4f n0 = cnodes[4 * w.cur];
-    const v4f n1 = cnodes[4 * w.cur + 1];
+    constexpr uint32_t kNodeQuads = AABB_MODE == kAabbClean ? 2 : 4;  // clean trees: 32-byte nodes holding the primitive box alone
+    const v4f n0 = cnodes[kNodeQuads * w.cur];
+    const v4f n1 = cnodes[kNodeQuads * w.cur + 1];
     bool inside;
     if (sc.is_list) inside = true;
     else if (AABB_MODE == kAabbClean) {
-        const v4f b0 = cnodes[4 * w.cur + 2], b1 = cnodes[4 * w.cur + 3];
-        inside = box_overlap(xyz(b0), xyz(b1), r.o, w.inv, t_min, w.h.t);
+        inside = box_overlap(xyz(n0), xyz(n1), r.o, w.inv, t_min, w.h.t);
     } else if (AABB_MODE == RRT_AABB_TIGHT) {
         const v4f b0 = cnodes[4 * w.cur + 2], b1 = cnodes[4 * w.cur + 3];
         inside = box_overlap(xyz(b0), xyz(b1), r.o, w.inv, t_min, w.h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, w.inv, t_min, w.h.t);
