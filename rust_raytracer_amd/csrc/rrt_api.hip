@@ -642,6 +642,7 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     if (rc) return rc;
     rrt_scene* s = new rrt_scene();
     HIP_TRY(hipGetDevice(&s->device));
+    uint32_t clean_depth = 0;  // clean trees: deepest inner node of the device tree (sizes the traversal stack)
 #define UP(field, src, count)                                                        \
     do {                                                                             \
         rc = upload(src, count, (const void**)&s->d.field, &s->owned);               \
@@ -759,13 +760,101 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             n.b = RRT_LEAF_FLAG | ((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair);
         }
         const std::vector<float> tb = tight_boxes(desc);
-        if (clean) {  // 32-byte nodes: the primitive box with the links in the fourth lanes
-            std::vector<float> rec((size_t)dn.size() * 8);
-            for (size_t i = 0; i < dn.size(); ++i) {
-                std::memcpy(&rec[i * 8], &tb[i * 8], 12);
-                std::memcpy(&rec[i * 8 + 3], &dn[i].a, 4);
-                std::memcpy(&rec[i * 8 + 4], &tb[i * 8 + 4], 12);
-                std::memcpy(&rec[i * 8 + 7], &dn[i].b, 4);
+        if (clean) {
+            // Inner nodes only, 64 bytes each, holding BOTH children's primitive boxes and links (see walk_step): a link is an
+            // inner node's number or kLinkLeaf | (pairs - 1) << 28 | first pair.  A leaf of more than 8 pair records (shapes
+            // the sweep would not separate) is hung under extra inner nodes that halve its range.
+            std::vector<float> rec;
+            auto pair_range_box = [&](uint32_t first, uint32_t count, float* b) {  // pair boxes are stored (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z)
+                const float inf = std::numeric_limits<float>::infinity();
+                b[0] = b[1] = b[2] = inf;
+                b[4] = b[5] = b[6] = -inf;
+                for (uint32_t k = first; k < first + count; ++k) {
+                    const float* pb = &pairs[(size_t)k * 4 * kPairQuads + 24];
+                    for (int c = 0; c < 3; ++c) {
+                        b[c] = std::fmin(b[c], pb[2 * c]);
+                        b[4 + c] = std::fmax(b[4 + c], pb[2 * c + 1]);
+                    }
+                }
+            };
+            struct Pending { uint32_t node; bool is_range; uint32_t first, count; uint32_t parent, depth; };
+            auto new_inner = [&]() {
+                rec.resize(rec.size() + 16, 0.0f);
+                return (uint32_t)(rec.size() / 16 - 1);
+            };
+            auto set_child = [&](uint32_t parent, uint32_t side, const float* box, uint32_t link) {
+                float* r = &rec[(size_t)parent * 16 + (side ? 8 : 0)];
+                std::memcpy(r, box, 12);
+                std::memcpy(r + 4, box + 4, 12);
+                std::memcpy(&rec[(size_t)parent * 16 + (side ? 7 : 3)], &link, 4);  // left link in quad 0, right link in quad 1
+            };
+            // links of quad 1.w (right link) and quad 2.w (axis) share no slot with the right box: quad 2 = (right lo, axis), quad 3 = (right hi, -)
+            std::vector<Pending> todo;
+            uint32_t root_link = 0;
+            auto link_of = [&](uint32_t node, bool is_range, uint32_t first, uint32_t count, uint32_t* out_link) -> bool {
+                // returns true when the child is a leaf small enough for a direct link
+                if (!is_range) {
+                    const rrt_node& n = dn[node];
+                    if (!(n.b & RRT_LEAF_FLAG)) return false;
+                    first = n.a;
+                    count = n.b & ~RRT_LEAF_FLAG;
+                }
+                if (count > 8 || first > 0x0fffffffu) return false;
+                *out_link = kLinkLeaf | ((count - 1u) << 28) | first;
+                return true;
+            };
+            if ((uint64_t)pairs.size() / (4 * kPairQuads) > 0x0fffffffull) {
+                rrt_scene_destroy(s);
+                return rrt_set_error(RRT_ERR_LIMIT, "clean tree: more than 2^28 pair records");
+            }
+            if (!dn.empty()) {
+                uint32_t link;
+                if (link_of(0, false, 0, 0, &link)) root_link = link;
+                else {
+                    root_link = new_inner();
+                    todo.push_back({0u, (dn[0].b & RRT_LEAF_FLAG) != 0, dn[0].a, dn[0].b & ~RRT_LEAF_FLAG, root_link, 1u});
+                }
+            }
+            // each entry: fill inner node `parent` (already allocated) from tree node `node` (or from a pair range)
+            while (!todo.empty()) {
+                const Pending it = todo.back();
+                todo.pop_back();
+                const uint32_t self = it.parent;
+                if (it.depth > clean_depth) clean_depth = it.depth;
+                uint32_t axis = 0;
+                struct Child { uint32_t node; bool is_range; uint32_t first, count; float box[8]; } ch[2];
+                if (it.is_range) {  // an oversized leaf: halve its pair range
+                    const uint32_t half = it.count / 2;
+                    ch[0] = {0u, true, it.first, half, {}};
+                    ch[1] = {0u, true, it.first + half, it.count - half, {}};
+                    pair_range_box(ch[0].first, ch[0].count, ch[0].box);
+                    pair_range_box(ch[1].first, ch[1].count, ch[1].box);
+                } else {
+                    const rrt_node& n = dn[it.node];
+                    axis = n.b;
+                    const uint32_t kids[2] = {it.node + 1u, n.a};
+                    for (int k = 0; k < 2; ++k) {
+                        const rrt_node& c = dn[kids[k]];
+                        const bool leaf = (c.b & RRT_LEAF_FLAG) != 0;
+                        ch[k] = {kids[k], false, leaf ? c.a : 0u, leaf ? (c.b & ~RRT_LEAF_FLAG) : 0u, {}};
+                        std::memcpy(ch[k].box, &tb[(size_t)kids[k] * 8], 32);
+                    }
+                }
+                for (uint32_t k = 0; k < 2; ++k) {
+                    uint32_t link;
+                    const bool leaf_node = !ch[k].is_range && (dn[ch[k].node].b & RRT_LEAF_FLAG) != 0;
+                    if (!link_of(ch[k].node, ch[k].is_range, ch[k].first, ch[k].count, &link)) {
+                        link = new_inner();
+                        todo.push_back({ch[k].node, ch[k].is_range || leaf_node, ch[k].first, ch[k].count, link, it.depth + 1u});
+                    }
+                    set_child(self, k, ch[k].box, link);
+                }
+                std::memcpy(&rec[(size_t)self * 16 + 11], &axis, 4);
+            }
+            s->d.root_link = root_link;
+            if (clean_depth + 1u > kMaxStackDepth) {
+                rrt_scene_destroy(s);
+                return rrt_set_error(RRT_ERR_LIMIT, "clean tree needs more than 64 pending stack entries per ray");
             }
             UP(nodes, (const float4*)rec.data(), rec.size() / 4);
         } else {
@@ -799,6 +888,7 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     s->res_y = desc->resolution_y;
     s->samples = desc->samples;
     s->stack_depth = desc->bvh_depth ? desc->bvh_depth : 1;
+    if (desc->aggregate_kind == RRT_AGGREGATE_BVH_CLEAN) s->stack_depth = clean_depth + 1u;
     s->n_textures = desc->n_textures;
     s->deep = desc->n_nodes > kDeepTreeNodes || s->clean;  // the clean mode's tie rule lives in the cooperative-leaf walk only
     // which code the scene needs (see F_* in rrt_device.hpp)

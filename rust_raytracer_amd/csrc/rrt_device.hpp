@@ -205,7 +205,9 @@ RRT_DEV f3 xyz(v4f q) { return f3{q.x, q.y, q.z}; }
 struct DScene {
     const float4* nodes;      // 4 x float4 per node: the rrt_node (a leaf's `a` holds its first PAIR index), then the padded
                               // box its primitives occupy (lo, hi), which the TIGHT traversal tests as well: one 64-byte line.
-                              // Clean trees: 2 x float4 per node, (box lo, a), (box hi, b) with the primitive box only
+                              // Clean trees: inner nodes only, 4 x float4 each: (left box lo, left link), (left box hi, right link),
+                              // (right box lo, cut axis), (right box hi, -); a link is an inner node's index, or
+                              // kLinkLeaf | (pairs - 1) << 28 | first pair
     const float4* pairs;      // kPairQuads x float4 per two consecutive primitives of a leaf (see triangle_pair_eval)
     const float4* slots;      // 3 x float4 per rrt_slot
     const float4* tri_shade;  // 4 x float4 per rrt_tri_shade
@@ -218,6 +220,7 @@ struct DScene {
     const uint8_t* texels;
     const rrt_light* lights;
     uint32_t n_nodes, n_slots, n_lights, is_list;
+    uint32_t root_link;  // clean trees: where the walk starts (see walk_step)
     rrt_camera cam;
 
     RRT_DEV cv4p c_nodes() const { return (cv4p)(const void*)nodes; }
@@ -585,6 +588,7 @@ RRT_DEV bool pair_box_overlap(v2f_ x, v2f_ y, v2f_ z, f3 inv, f3 noi, float t_mi
 // tested with the ordinary interval test on their primitive boxes alone, and equal distances go to the shape that comes
 // first in SCENE order - together exactly what the reference's List aggregate returns (aggregate.rs:142-165).
 constexpr int kAabbClean = 2;
+constexpr uint32_t kLinkLeaf = 0x80000000u;  // clean trees: a child link that names a leaf's pair records directly
 
 // ---- scene features a kernel variant is compiled for ------------------------------------------------------------------
 // The host picks the smallest variant that covers the scene, so scenes without media / image textures / bump maps do not
@@ -873,7 +877,7 @@ RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, fl
     w.h.t = t_max;
     w.h.u = w.h.v = w.h.det = 0.0f;
     w.sp = 0;
-    w.cur = 0;
+    w.cur = sc.root_link;  // 0 for the reference's trees
     w.pending = false;
     w.first_pair = w.n_pairs = 0;
     w.running = active && sc.n_nodes != 0;
@@ -884,14 +888,41 @@ RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, fl
 template <int AABB_MODE>
 RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, uint32_t* stack, uint32_t stride) {
     const cv4p cnodes = sc.c_nodes();
-    constexpr uint32_t kNodeQuads = AABB_MODE == kAabbClean ? 2 : 4;  // clean trees: 32-byte nodes holding the primitive box alone
-    const v4f n0 = cnodes[kNodeQuads * w.cur];
-    const v4f n1 = cnodes[kNodeQuads * w.cur + 1];
+    if (AABB_MODE == kAabbClean) {
+        // One fetch brings both children's boxes: only children the ray meets are ever fetched themselves, and leaves are
+        // not fetched at all (their pair range sits in the link).
+        if (w.cur & kLinkLeaf) {
+            w.pending = true;
+            w.running = false;
+            w.first_pair = w.cur & 0x0fffffffu;
+            w.n_pairs = ((w.cur >> 28) & 7u) + 1u;
+            return;
+        }
+        const v4f l0 = cnodes[4 * w.cur], l1 = cnodes[4 * w.cur + 1], r0 = cnodes[4 * w.cur + 2], r1 = cnodes[4 * w.cur + 3];
+        const bool hit_l = box_overlap(xyz(l0), xyz(l1), r.o, w.inv, t_min, w.h.t);
+        const bool hit_r = box_overlap(xyz(r0), xyz(r1), r.o, w.inv, t_min, w.h.t);
+        const uint32_t link_l = __float_as_uint(l0.w), link_r = __float_as_uint(l1.w), axis = __float_as_uint(r0.w);
+        const float dax = axis == 0u ? r.d.x : (axis == 1u ? r.d.y : r.d.z);
+        const bool left_first = !(dax < 0.0f);  // the left child holds the lower centres: nearer when the ray runs upwards
+        if (hit_l && hit_r) {
+            stack[w.sp * stride] = left_first ? link_r : link_l;
+            ++w.sp;
+            w.cur = left_first ? link_l : link_r;
+        } else if (hit_l || hit_r) {
+            w.cur = hit_l ? link_l : link_r;
+        } else if (w.sp == 0) {
+            w.running = false;
+        } else {
+            --w.sp;
+            w.cur = stack[w.sp * stride];
+        }
+        return;
+    }
+    const v4f n0 = cnodes[4 * w.cur];
+    const v4f n1 = cnodes[4 * w.cur + 1];
     bool inside;
     if (sc.is_list) inside = true;
-    else if (AABB_MODE == kAabbClean) {
-        inside = box_overlap(xyz(n0), xyz(n1), r.o, w.inv, t_min, w.h.t);
-    } else if (AABB_MODE == RRT_AABB_TIGHT) {
+    else if (AABB_MODE == RRT_AABB_TIGHT) {
         const v4f b0 = cnodes[4 * w.cur + 2], b1 = cnodes[4 * w.cur + 3];
         inside = box_overlap(xyz(b0), xyz(b1), r.o, w.inv, t_min, w.h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, w.inv, t_min, w.h.t);
     } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, w.inv, t_min, w.h.t);
@@ -900,7 +931,7 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, uin
         // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
         const float dax = b == 0u ? r.d.x : (b == 1u ? r.d.y : r.d.z);
         const uint32_t left = w.cur + 1u, right = a;
-        const bool left_first = AABB_MODE == kAabbClean ? !(dax < 0.0f) : dax < 0.0f;  // clean: the nearer child first
+        const bool left_first = dax < 0.0f;
         stack[w.sp * stride] = left_first ? right : left;
         ++w.sp;
         w.cur = left_first ? left : right;

@@ -212,7 +212,7 @@ def test_one_big_leaf_with_ties_bit_exact(gpu, aggregate, n):
         assert st["rays"] == int(st_ref[0])
 
 
-@pytest.mark.parametrize("case", ["terrain", "slats", "spheres"])
+@pytest.mark.parametrize("case", ["terrain", "slats", "spheres", "coincident"])
 def test_clean_bvh_returns_what_the_list_aggregate_returns(gpu, case):
     """RRT_AGGREGATE_BVH_CLEAN (a tree of its own, built on the device) against the oracle's LIST aggregate: nearest hit, equal
     distances to the shape that is first in scene order, bit-exact distances; rendered frames bit-exact too."""
@@ -220,6 +220,9 @@ def test_clean_bvh_returns_what_the_list_aggregate_returns(gpu, case):
         d = synth.terrain_desc(60, seed=3, width=40, height=40, samples=2)
     elif case == "slats":
         d = synth.slats_desc(n=40, aggregate=0)  # shapes duplicated in place: exact ties
+    elif case == "coincident":
+        d = synth.slats_desc(n=6, aggregate=0, spheres=1)  # 14 copies of one quad: a leaf no sweep can split (28 triangles)
+        d["shapes"] = d["shapes"][:2] + [dict(d["shapes"][2], material=i % 3) for i in range(14)] + d["shapes"][2:]
     else:
         d = synth.spheres_desc(media=6)
     o = orc.OracleScene(dict(d, aggregate=0))
