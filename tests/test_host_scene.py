@@ -192,6 +192,22 @@ def test_builder_api_and_list_aggregate():
         hs.add_material(0, 99)
 
 
+def test_device_built_aggregates_fail_loudly_without_a_gpu():
+    """RRT_AGGREGATE_BVH_GPU / _BVH_CLEAN are built on the device; there is no host fallback behind them."""
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import synth
+
+    d = synth.slats_desc(n=3, aggregate=1)
+    for kind in ("BVH_GPU", "BVH_CLEAN"):
+        with pytest.raises(rrt.RrtError, match="BVH build"):
+            synth.host_scene(d, kind)
+    hs = rrt.HostScene.new()
+    assert rrt.lib().rrt_host_finalize(hs._h, 7) != 0  # unknown aggregate kind
+
+
 def test_synthetic_mesh_bvh_matches_oracle_at_scale():
     """A 20k-triangle soup: the product's in-place range builder and the oracle's recursive builder give the same tree."""
     rng = np.random.default_rng(1)
