@@ -49,7 +49,7 @@ typedef struct rrt_node {
  * aggregate.rs:144-165, walks a leaf).
  *   triangle: v0, e1 = v1 - v0, e2 = v2 - v0 (the f32 differences Triangle::hit forms, shape.rs:340-341)
  *   sphere / medium: v0,e1,e2 unused; aux = index into spheres[] / media[]
- * info: bits 0..23 material index, bit 28 backface culling, bits 30..31 kind. */
+ * info: bits 0..23 material index, bit 28 backface culling, bits 30..31 kind; bits 24..27 and 29 are reserved (ignored). */
 typedef struct rrt_slot {
     float v0[3];
     uint32_t prim; /* index of the shape in scene order (what Aggregate::hit's &SyncShape identifies) */
