@@ -217,6 +217,11 @@ typedef struct rrt_stats {
  * Logistics overrides: pass 0 / NaN to keep the file's value. */
 int rrt_host_scene_load(const char* scene_json_path, uint32_t override_width, uint32_t override_height, uint32_t override_samples,
                         float override_aspect, rrt_host_scene** out);
+/* The same, choosing what the file's "BVH" aggregate becomes: RRT_AGGREGATE_BVH (the reference's tree, built on the host),
+ * RRT_AGGREGATE_BVH_GPU (the same tree, built on the device) or RRT_AGGREGATE_BVH_CLEAN (see rrt_host_finalize).  A "List"
+ * stays a list.  No counterpart in the reference, whose files have no such choice. */
+int rrt_host_scene_load_as(const char* scene_json_path, uint32_t override_width, uint32_t override_height, uint32_t override_samples,
+                           float override_aspect_ratio, int bvh_kind, rrt_host_scene** out);
 /* Programmatic construction, one call per scene.rs deserialize_* function. Indices returned through *id. */
 int rrt_host_scene_new(rrt_host_scene** out);
 int rrt_host_add_texture(rrt_host_scene*, const rrt_texture* t, const uint8_t* texels /* Image only: w*h*channels bytes */, int32_t* id);

@@ -110,6 +110,7 @@ def lib():
     L.rrt_last_error.restype = C.c_char_p
     L.rrt_version.restype = C.c_char_p
     L.rrt_host_scene_load.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.POINTER(vp)]
+    L.rrt_host_scene_load_as.argtypes = [C.c_char_p, C.c_uint32, C.c_uint32, C.c_uint32, C.c_float, C.c_int, C.POINTER(vp)]
     L.rrt_host_scene_new.argtypes = [C.POINTER(vp)]
     L.rrt_host_add_texture.argtypes = [vp, C.POINTER(_Texture), vp, C.POINTER(C.c_int32)]
     L.rrt_host_add_material.argtypes = [vp, C.c_uint32, C.c_int32, C.c_int32, C.c_float, C.POINTER(C.c_int32)]
@@ -160,9 +161,12 @@ class HostScene:
         self._h = handle
 
     @classmethod
-    def load(cls, path, width=0, height=0, samples=0, aspect_ratio=float("nan")):
+    def load(cls, path, width=0, height=0, samples=0, aspect_ratio=float("nan"), tree="BVH"):
+        """tree: what the file's "BVH" aggregate becomes - "BVH" (reference tree, host build), "BVH_GPU" (same tree, device build)
+        or "BVH_CLEAN" (clean tree with the List aggregate's results)."""
         h = C.c_void_p()
-        _check(lib().rrt_host_scene_load(os.fsencode(path), width, height, samples, aspect_ratio, C.byref(h)))
+        _check(lib().rrt_host_scene_load_as(os.fsencode(path), width, height, samples, aspect_ratio, {"BVH": 1, "BVH_GPU": 2, "BVH_CLEAN": 3}[tree],
+                                            C.byref(h)))
         return cls(h)
 
     @classmethod
@@ -287,8 +291,8 @@ class Scene:
         self._h = h
 
     @classmethod
-    def load(cls, path, width=0, height=0, samples=0, aspect_ratio=float("nan")):
-        return cls(HostScene.load(path, width, height, samples, aspect_ratio))
+    def load(cls, path, width=0, height=0, samples=0, aspect_ratio=float("nan"), tree="BVH"):
+        return cls(HostScene.load(path, width, height, samples, aspect_ratio, tree))
 
     def hit(self, origins, directions, t_min=T_MIN, t_max=T_MAX, aabb_mode=AABB_TIGHT, seed=0):
         """Aggregate::hit for a batch of rays: (prim_id int32[n] with -1 = miss, t float32[n])."""

@@ -65,6 +65,8 @@ struct Progress {
                  "        --background <black|sky>         Colour of rays that leave the scene (default black)\n"
                  "        --seed <N>                       Seed of the per-sample random streams (default 0)\n"
                  "        --aabb <tight|reference>         Bounding-box test of the BVH walk (default tight)\n"
+                 "        --tree <host|gpu|clean>          Where and how a \"BVH\" aggregate is built: the reference's tree on the host\n"
+                 "                                         (default) or on the GPU, or the clean tree with the List aggregate's results\n"
                  "        --samples <N> --width <N> --height <N>   Override the scene's Logistics\n\nARGS:\n"
                  "    <IN_SCENE_FILE>    The scene specification to render\n"
                  "    <OUT_FILEPATH>     The relative filepath to write the output image to\n",
@@ -86,6 +88,7 @@ bool parse_u32(const char* s, uint32_t* out) {
 int main(int argc, char** argv) {
     const char* thread_count = "2";
     uint32_t seed = 0, bg = RRT_BG_BLACK, aabb = RRT_AABB_TIGHT, o_samples = 0, o_width = 0, o_height = 0;
+    int tree = RRT_AGGREGATE_BVH;
     std::vector<const char*> positional;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -109,6 +112,12 @@ int main(int argc, char** argv) {
             if (v == "tight") aabb = RRT_AABB_TIGHT;
             else if (v == "reference") aabb = RRT_AABB_REFERENCE;
             else usage("--aabb takes tight or reference");
+        } else if (a == "--tree") {
+            std::string v = value("--tree");
+            if (v == "host") tree = RRT_AGGREGATE_BVH;
+            else if (v == "gpu") tree = RRT_AGGREGATE_BVH_GPU;
+            else if (v == "clean") tree = RRT_AGGREGATE_BVH_CLEAN;
+            else usage("--tree takes host, gpu or clean");
         } else if (a == "-h" || a == "--help") usage("help requested");
         else if (a.size() > 1 && a[0] == '-') usage(("Found argument '" + a + "' which wasn't expected, or isn't valid in this context").c_str());
         else positional.push_back(argv[i]);
@@ -123,7 +132,7 @@ int main(int argc, char** argv) {
     if (num_threads == 0) die("Need a thread count greater than zero");
 
     rrt_host_scene* host = nullptr;  // main.rs:77-95
-    if (rrt_host_scene_load(positional[0], o_width, o_height, o_samples, NAN, &host) != RRT_OK)
+    if (rrt_host_scene_load_as(positional[0], o_width, o_height, o_samples, NAN, tree, &host) != RRT_OK)
         die(std::string("Failed to parse scene spec JSON.: ") + rrt_last_error());
     const rrt_scene_desc* desc = rrt_host_desc(host);
     const uint32_t W = desc->resolution_x, H = desc->resolution_y, spp = desc->samples;

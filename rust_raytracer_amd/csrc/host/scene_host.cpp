@@ -422,9 +422,13 @@ int rrt_host_scene_new(rrt_host_scene** out) {
 void rrt_host_scene_destroy(rrt_host_scene* s) { delete s; }
 
 int rrt_host_scene_load(const char* path, uint32_t ow, uint32_t oh, uint32_t os, float oaspect, rrt_host_scene** out) {
+    return rrt_host_scene_load_as(path, ow, oh, os, oaspect, RRT_AGGREGATE_BVH, out);
+}
+int rrt_host_scene_load_as(const char* path, uint32_t ow, uint32_t oh, uint32_t os, float oaspect, int tree, rrt_host_scene** out) {
     RRT_NEED(path && out);
+    RRT_NEED(tree == RRT_AGGREGATE_BVH || tree == RRT_AGGREGATE_BVH_GPU || tree == RRT_AGGREGATE_BVH_CLEAN);
     rrt_host_scene* s = new rrt_host_scene();
-    std::string e = rrt_host::load_scene_file(path, ow, oh, os, oaspect, &s->b);
+    std::string e = rrt_host::load_scene_file(path, ow, oh, os, oaspect, tree, &s->b);
     if (!e.empty()) {
         delete s;
         return fail_scene(e);

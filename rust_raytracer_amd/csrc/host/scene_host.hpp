@@ -58,7 +58,8 @@ struct SceneBuild {
 };
 
 // scene file -> SceneBuild (scene.rs:64-159); returns "" or the error text
-std::string load_scene_file(const std::string& path, uint32_t ow, uint32_t oh, uint32_t os, float oaspect, SceneBuild* out);
+// tree: what the file's "BVH" aggregate becomes (RRT_AGGREGATE_BVH, _BVH_GPU or _BVH_CLEAN)
+std::string load_scene_file(const std::string& path, uint32_t ow, uint32_t oh, uint32_t os, float oaspect, int tree, SceneBuild* out);
 
 // Decodes an image file to 8-bit texels with 1 (grey) or 3 (RGB) channels; returns "" or the error text.
 std::string decode_image_file(const std::string& path, uint32_t* w, uint32_t* h, uint32_t* channels, std::vector<uint8_t>* px);

@@ -452,7 +452,7 @@ struct Loader {
 
 }  // namespace
 
-std::string load_scene_file(const std::string& path, uint32_t ow, uint32_t oh, uint32_t os, float oaspect, SceneBuild* out) {
+std::string load_scene_file(const std::string& path, uint32_t ow, uint32_t oh, uint32_t os, float oaspect, int tree, SceneBuild* out) {
     bool ok;
     std::string text = read_file(path, &ok);
     if (!ok) return "Failed to read scene spec file.";
@@ -496,7 +496,8 @@ std::string load_scene_file(const std::string& path, uint32_t ow, uint32_t oh, u
         const Json& agg = required(top, "Aggregate");
         if (agg.kind != Json::String) bail("'Aggregate' is not a string.");
         if (agg.str != "List" && agg.str != "BVH") bail("Unknown Aggregate 'type' " + agg.str + " given.");
-        std::string e = out->finalize(agg.str == "BVH" ? RRT_AGGREGATE_BVH : RRT_AGGREGATE_LIST);
+        // `tree` says where and how a "BVH" is built; a "List" stays a list
+        std::string e = out->finalize(agg.str == "BVH" ? tree : RRT_AGGREGATE_LIST);
         if (!e.empty()) bail(e);
     } catch (const LoadError& e) {
         return e.msg;

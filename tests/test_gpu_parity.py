@@ -242,6 +242,21 @@ def test_clean_bvh_returns_what_the_list_aggregate_returns(gpu, case):
     assert st["rays"] == int(st_ref[0])
 
 
+def test_scene_file_with_a_device_built_or_clean_tree(gpu):
+    """rrt_host_scene_load_as: the asset files rendered with the tree built on the device (bit-identical to the host build) and
+    with the clean tree (the oracle's List aggregate; on these scenes also the BVH's frame)."""
+    name, W, H, spp = "Cornell_Box.json", 40, 40, 4
+    import sceneio
+    o_list = orc.OracleScene(dict(sceneio.read_scene(orc.asset(name), {"resolution_x": W, "resolution_y": H, "samples": spp}), aggregate=0))
+    ref_list, _ = o_list.render(W, H, spp, seed=2)
+    host, _ = rrt.Scene.load(orc.asset(name), width=W, height=H, samples=spp).render(seed=2)
+    dev, _ = rrt.Scene.load(orc.asset(name), width=W, height=H, samples=spp, tree="BVH_GPU").render(seed=2)
+    clean, _ = rrt.Scene.load(orc.asset(name), width=W, height=H, samples=spp, tree="BVH_CLEAN").render(seed=2)
+    assert np.array_equal(bits(host), bits(dev))
+    same = (bits(clean) == bits(ref_list)) | (np.isnan(clean) & np.isnan(ref_list))
+    assert same.all()
+
+
 def _same_records(a, b):
     return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
 
