@@ -120,6 +120,25 @@ def slats_desc(n=40, seed=5, width=40, height=32, samples=3, aggregate=0, sphere
     }
 
 
+def lone_light_desc(width=48, height=40, samples=16):
+    """A Lambert sphere and an emissive sphere, both stretched upwards so that they stick out of the boxes the reference gives
+    them (shape.rs:129-139), seen from below: two shapes, i.e. a BVH of a single leaf; paths bounce off the Lambert sphere's
+    bulge above the leaf's box, and rays from there to the light's bulge never meet that box."""
+    return {
+        "logistics": {"resolution_x": width, "resolution_y": height, "samples": samples, "use_importance_sampling": True},
+        "camera": {"position": [0.0, -3.0, 3.0], "look_at": [0.0, 1.3, 0.0], "up": [0.0, 1.0, 0.0], "fov": 40.0,
+                   "aspect_ratio": width / height, "aperture": 0.0, "focus_distance": 1.0},
+        "textures": [{"type": sceneio.TEX_CONSTANT, "color": [0.7, 0.6, 0.5]}, {"type": sceneio.TEX_CONSTANT, "color": [5.0, 4.0, 3.0]}],
+        "materials": [{"type": sceneio.MAT_LAMBERT, "albedo": 0, "bump": -1, "param": 0.0},
+                      {"type": sceneio.MAT_DIFFUSE_LIGHT, "albedo": 1, "bump": -1, "param": 0.0}],
+        "shapes": [
+            {"type": "sphere", "radius": 0.5, "material": 0, "transform": ([-0.8, 1.0, 0.0], [0.0, 15.0, 0.0], [1.0, 3.0, 1.0])},
+            {"type": "sphere", "radius": 0.5, "material": 1, "transform": ([0.8, 1.0, 0.0], [0.0, -25.0, 0.0], [1.0, 3.0, 1.0])},
+        ],
+        "aggregate": 1,
+    }
+
+
 def host_scene(desc, aggregate=None):
     """The product's host-side scene for a neutral description (constant textures, meshes and spheres).
     aggregate: "List", "BVH" (built on the host) or "BVH_GPU" (built on the device); default: what the description asks for."""

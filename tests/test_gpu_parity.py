@@ -242,6 +242,29 @@ def test_clean_bvh_returns_what_the_list_aggregate_returns(gpu, case):
     assert st["rays"] == int(st_ref[0])
 
 
+def test_light_densities_come_from_the_shape_not_from_the_tree(gpu):
+    """Single-leaf scene whose light (a scaled sphere) sticks out of the leaf's box: the reference's tree misses it there, but
+    Sphere::pdf (shape.rs:141-147) asks the sphere itself; the harvesting kernel must reproduce both."""
+    d = synth.lone_light_desc()
+    o = orc.OracleScene(d)
+    hs = synth.host_scene(d)
+    assert hs.desc.n_nodes == 1 and hs.desc.n_lights == 1
+    g = rrt.Scene(hs)
+    W, H, spp = 48, 40, 16
+    ro, rd = raygen.ray_batch(o, W, H, n_random=4000, seed=21)
+    p_ref, t_ref = o.intersect(ro, rd)
+    p_list, _ = orc.OracleScene(dict(d, aggregate=0)).intersect(ro, rd)
+    assert (p_ref != p_list).sum() > 10, "the leaf's box should hide part of the sphere from the tree"
+    ref, st_ref = o.render(W, H, spp, seed=9)
+    for mode in (rrt.AABB_TIGHT, rrt.AABB_REFERENCE):
+        p, t = g.hit(ro, rd, aabb_mode=mode)
+        assert np.array_equal(p, p_ref) and np.array_equal(bits(t), bits(t_ref))
+        img, st = g.render(seed=9, aabb_mode=mode)
+        same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), "%d of %d values differ (mode %d)" % ((~same).sum(), same.size, mode)
+        assert st["rays"] == int(st_ref[0])
+
+
 def test_scene_file_with_a_device_built_or_clean_tree(gpu):
     """rrt_host_scene_load_as: the asset files rendered with the tree built on the device (bit-identical to the host build) and
     with the clean tree (the oracle's List aggregate; on these scenes also the BVH's frame)."""
