@@ -99,7 +99,7 @@ def main():
             img.zero_()
         if ev0 is not None:
             ev0.record(stream)
-        scene.render_device(img.data_ptr(), counters.data_ptr(), stream.cuda_stream, **kw)
+        scene.render_device(img.data_ptr(), counters.data_ptr(), stream.cuda_stream, out_floats=img.numel(), **kw)
         if ev1 is not None:
             ev1.record(stream)
         shard.reduce_frame(img, dst=0)  # the one collective of the job (no-op on one GPU)

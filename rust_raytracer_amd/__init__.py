@@ -324,7 +324,12 @@ class Scene:
         return img, {"rays": st.rays, "paths": st.paths, "seconds": st.render_seconds}
 
     def render_device(self, d_rgb_sum, d_counters=0, stream=0, **kw):
-        """Enqueues the render on `stream` into a device buffer (raw pointers as ints); does not synchronise."""
+        """Enqueues the render on `stream` into a device buffer (raw pointers as ints); does not synchronise.
+        The buffer must hold height x width x 3 floats of the frame that is rendered (the scene's Logistics unless width / height
+        are given); pass out_floats = its size to have that checked here - the library cannot see how large a device buffer is."""
+        W, H = kw.get("width") or self.width, kw.get("height") or self.height
+        if "out_floats" in kw and kw["out_floats"] < W * H * 3:
+            raise ValueError("the output buffer holds %d floats, the %dx%d frame needs %d" % (kw["out_floats"], W, H, W * H * 3))
         p = self._params(kw.get("width"), kw.get("height"), kw.get("samples"), kw.get("first_sample", 0), kw.get("seed", 0),
                          kw.get("background", BG_BLACK), kw.get("max_depth", -1), kw.get("aabb_mode", AABB_TIGHT), kw.get("tile_count", 1),
                          kw.get("tile_index", 0), kw.get("accumulate", False))
