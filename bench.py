@@ -169,7 +169,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "kernel": "k_trace", "kernel_ms": k_s * 1e3, "launches_per_step": launches / max(args.steps, 1),
                          "bytes_per_ray": BYTES_PER_RAY, "rays_per_launch": rays_per_launch,
-                         "accumulate_ms_per_step": accumulate_ms / max(args.steps, 1), "render_ms_per_step": float(np.mean(render_ms))},
+                         "accumulate_ms_per_step": accumulate_ms / max(args.steps, 1), "render_ms_per_step": float(np.mean(render_ms)),
+                         "limiter": "vector ALU issue: SQ_ACTIVE_INST_VALU covers the whole launch (profiles/r01_d_summary.md); "
+                                    "the 192 B/ray figure is what a queue-based tracer would move, this kernel moves 3.4 B/ray"},
         }
         if world == 1 and args.cpu_spp > 0:
             out["cpu_baseline"] = cpu_baseline(args.cpu_spp)
