@@ -1,0 +1,199 @@
+// Exact reciprocal, the primitive intersection tests (shape.rs, volume.rs) and the bounding-box tests (aggregate.rs:471-503).
+// Each function names the reference code it computes (paths relative to the reference root).
+#pragma once
+#include "rrt_scene_view.hpp"
+
+namespace rrt {
+
+// ---- exact reciprocal ------------------------------------------------------------------------------------------
+// 1.0f / x, correctly rounded: the hardware reciprocal estimate plus one fused Newton step, accepted when the step's
+// residual e = 1 - x*r0 is small.  On gfx950 that is exact for every float whose residual passes (all normal x whose
+// reciprocal is normal; zero, denormal, huge and non-finite x fail the residual test and take the full division);
+// rrt_selftest_reciprocal repeats the exhaustive comparison with IEEE division over all 2^32 bit patterns.
+#define RRT_RCP_RESIDUAL 9.5367431640625e-07f  // 2^-20
+RRT_DEV float exact_rcp(float x) {
+#ifdef RRT_RCP_RANGE
+    if (__builtin_fabsf(x) >= 7.888609052210118e-31f && __builtin_fabsf(x) <= 1.2676506002282294e30f) {
+        const float r0 = __builtin_amdgcn_rcpf(x);
+        const float e = __builtin_fmaf(-x, r0, 1.0f);
+        return __builtin_fmaf(e, r0, r0);
+    }
+    return 1.0f / x;
+#else
+    const float r0 = __builtin_amdgcn_rcpf(x);
+    const float e = __builtin_fmaf(-x, r0, 1.0f);
+    if (__builtin_fabsf(e) <= RRT_RCP_RESIDUAL) return __builtin_fmaf(e, r0, r0);
+    return 1.0f / x;
+#endif
+}
+
+// ---- primitives ----------------------------------------------------------------------------------------------
+// Triangle::hit (shape.rs:335-372) on a slot holding v0, e1 = v1 - v0, e2 = v2 - v0.
+RRT_DEV bool triangle_hit(f3 v0, f3 e1, f3 e2, bool cull, const Ray& r, float t_min, float t_max, float* t_out) {
+    f3 p_vec = cross3(r.d, e2);
+    float det = dot3(e1, p_vec);
+    if (!cull && det > -RRT_EPS && det < RRT_EPS) return false;
+    else if (cull && det < RRT_EPS) return false;
+    float inv_det = exact_rcp(det);
+    f3 t_vec = r.o - v0;
+    float u = dot3(t_vec, p_vec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 q_vec = cross3(t_vec, e1);
+    float v = dot3(r.d, q_vec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t_hit = dot3(e2, q_vec) * inv_det;
+    if (t_hit < t_max && t_hit > t_min) {
+        *t_out = t_hit;
+        return true;
+    }
+    return false;
+}
+// The same test, also returning the determinant and barycentrics it computed; Triangle::get_hit_properties
+// (shape.rs:384-400) recomputes exactly these values from the same inputs, so they can be carried instead.
+RRT_DEV bool triangle_hit_uv(f3 v0, f3 e1, f3 e2, bool cull, const Ray& r, float t_min, float t_max, float* t_out, float* u_out, float* v_out,
+                             float* det_out) {
+    f3 p_vec = cross3(r.d, e2);
+    float det = dot3(e1, p_vec);
+    if (!cull && det > -RRT_EPS && det < RRT_EPS) return false;
+    else if (cull && det < RRT_EPS) return false;
+    float inv_det = exact_rcp(det);
+    f3 t_vec = r.o - v0;
+    float u = dot3(t_vec, p_vec) * inv_det;
+    if (u < 0.0f || u > 1.0f) return false;
+    f3 q_vec = cross3(t_vec, e1);
+    float v = dot3(r.d, q_vec) * inv_det;
+    if (v < 0.0f || u + v > 1.0f) return false;
+    float t_hit = dot3(e2, q_vec) * inv_det;
+    if (t_hit < t_max && t_hit > t_min) {
+        *t_out = t_hit;
+        *u_out = u;
+        *v_out = v;
+        *det_out = det;
+        return true;
+    }
+    return false;
+}
+// &Matrix4 * &Ray (matrix.rs:154-190) with a row-major 3x4
+template <class P>
+RRT_DEV Ray xform_ray(P m, const Ray& r) {
+    Ray o;
+    o.o = mk3(m[0] * r.o.x + m[1] * r.o.y + m[2] * r.o.z + m[3] * 1.0f, m[4] * r.o.x + m[5] * r.o.y + m[6] * r.o.z + m[7] * 1.0f,
+              m[8] * r.o.x + m[9] * r.o.y + m[10] * r.o.z + m[11] * 1.0f);
+    o.d = mk3(m[0] * r.d.x + m[1] * r.d.y + m[2] * r.d.z, m[4] * r.d.x + m[5] * r.d.y + m[6] * r.d.z,
+              m[8] * r.d.x + m[9] * r.d.y + m[10] * r.d.z);
+    return o;
+}
+template <class P>
+RRT_DEV f3 xform_vec(P m, f3 v) {
+    return mk3(m[0] * v.x + m[1] * v.y + m[2] * v.z, m[4] * v.x + m[5] * v.y + m[6] * v.z, m[8] * v.x + m[9] * v.y + m[10] * v.z);
+}
+template <class P>
+RRT_DEV f3 xform_point(P m, f3 p) {
+    return mk3(m[0] * p.x + m[1] * p.y + m[2] * p.z + m[3] * 1.0f, m[4] * p.x + m[5] * p.y + m[6] * p.z + m[7] * 1.0f,
+               m[8] * p.x + m[9] * p.y + m[10] * p.z + m[11] * 1.0f);
+}
+// Sphere::hit (shape.rs:65-85)
+template <class P>
+RRT_DEV bool sphere_hit_m(P w2l, float radius, const Ray& r, float t_min, float t_max, float* t_out) {
+    Ray lr = xform_ray(w2l, r);
+    f3 oc = lr.o - mk3(0.0f, 0.0f, 0.0f);
+    float a = dot3(lr.d, lr.d);
+    float b = 2.0f * dot3(oc, lr.d);
+    float c = dot3(oc, oc) - (radius * radius);
+    float disc = b * b - 4.0f * a * c;
+    if (disc > 0.0f) {
+        float t_hit = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
+        if (t_hit >= t_max || t_hit <= t_min) t_hit = (-b + __builtin_sqrtf(disc)) / (2.0f * a);
+        if (t_hit < t_max && t_hit > t_min) {
+            *t_out = t_hit;
+            return true;
+        }
+    }
+    return false;
+}
+RRT_DEV bool sphere_hit(csphere_p s, const Ray& r, float t_min, float t_max, float* t_out) {
+    return sphere_hit_m((cf1p)s->w2l, s->radius, r, t_min, t_max, t_out);
+}
+// The boundary shape of a medium: a sphere or a single triangle.
+RRT_DEV bool boundary_hit(const DScene& sc, cmedium_p m, const Ray& r, float t_min, float t_max, float* t_out) {
+    if (m->boundary_kind == RRT_KIND_SPHERE) return sphere_hit(sc.c_spheres() + m->boundary_index, r, t_min, t_max, t_out);
+    const cv4p bt = sc.c_btris() + 3 * m->boundary_index;
+    const v4f q0 = bt[0], q1 = bt[1], q2 = bt[2];
+    return triangle_hit(xyz(q0), xyz(q1), xyz(q2), (__float_as_uint(q1.w) & RRT_INFO_CULL) != 0, r, t_min, t_max, t_out);
+}
+// ConstantMedium::hit (volume.rs:65-102); xi is the uniform draw of line 95
+RRT_DEV bool medium_hit(const DScene& sc, cmedium_p m, const Ray& r, float t_min, float t_max, float xi, float* t_out) {
+    float t1, t2;
+    if (!boundary_hit(sc, m, r, -RRT_T_MAX, RRT_T_MAX, &t1)) return false;
+    if (!boundary_hit(sc, m, r, t1 + RRT_EPS, RRT_T_MAX, &t2)) return false;
+    if (t1 < t_min) t1 = t_min;
+    if (t2 > t_max) t2 = t_max;
+    if (t1 >= t2) return false;
+    if (t1 < 0.0f) t1 = 0.0f;
+    float distance_inside = (t2 - t1) * len3(r.d);
+    float hit_dist = (-1.0f / m->density) * det_log(xi);
+    if (hit_dist > distance_inside) return false;
+    *t_out = t1 + (hit_dist / len3(r.d));
+    return true;
+}
+
+// ---- bounding boxes (aggregate.rs:471-503) ---------------------------------------------------------------------
+RRT_DEV void slab(float lo, float hi, float o, float inv, float* t0, float* t1) {
+    float a = (lo - o) * inv;
+    float b = (hi - o) * inv;
+    bool neg = inv < 0.0f;
+    *t0 = neg ? b : a;
+    *t1 = neg ? a : b;
+}
+// AABB::intersect (aggregate.rs:471-503), the reference's test verbatim: an exit is honoured only against the running
+// ENTRY bound (`t1 < t_min`), so many boxes the ray misses are still accepted — and a few it hits are rejected, which the
+// reference's images depend on.  Both traversal modes apply it to the reference's boxes; TIGHT additionally requires
+// box_overlap() with the node's primitive box (see closest_hit).
+RRT_DEV bool aabb_reference(f3 bmin, f3 bmax, f3 o, f3 inv, float t_min, float t_max) {
+    float t0x, t1x, t0y, t1y, t0z, t1z;
+    slab(bmin.x, bmax.x, o.x, inv.x, &t0x, &t1x);
+    slab(bmin.y, bmax.y, o.y, inv.y, &t0y, &t1y);
+    slab(bmin.z, bmax.z, o.z, inv.z, &t0z, &t1z);
+    float lo = t0x > t_min ? t0x : t_min;
+    float hi = t1x < t_min ? t1x : t_max;
+    if (hi <= lo) return false;
+    float lo2 = t0y > lo ? t0y : lo;
+    float hi2 = t1y < lo ? t1y : hi;
+    if (hi2 <= lo2) return false;
+    float lo3 = t0z > lo2 ? t0z : lo2;
+    float hi3 = t1z < lo2 ? t1z : hi2;
+    return !(hi3 <= lo3);
+}
+
+// Does the ray's (t_min, t_max) span overlap the box?  The ordinary three-slab interval test; min/max drop NaNs (0 * inf
+// for a ray lying in a face plane), so such an axis constrains nothing and the test errs towards accepting.
+RRT_DEV bool box_overlap(f3 lo, f3 hi, f3 o, f3 inv, float t_min, float t_max) {
+    const float ax = (lo.x - o.x) * inv.x, bx = (hi.x - o.x) * inv.x;
+    const float ay = (lo.y - o.y) * inv.y, by = (hi.y - o.y) * inv.y;
+    const float az = (lo.z - o.z) * inv.z, bz = (hi.z - o.z) * inv.z;
+    const float t_near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), t_min));
+    const float t_far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
+    return t_near <= t_far;
+}
+
+// The same interval test against a pair record's box, which is stored interleaved (lo.x, hi.x | lo.y, hi.y | lo.z, hi.z) so
+// that both planes of an axis take one packed fused multiply-add: plane * inv + noi with noi = -(origin * inv).  Compared
+// with (plane - origin) * inv the result moves by a few ulps of |origin * inv|, i.e. by a few 1e-7 of the origin's
+// coordinate in space, far inside the padding of the boxes (1e-5 of the scene's extent, camera position included).
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+RRT_DEV bool pair_box_overlap(v2f_ x, v2f_ y, v2f_ z, f3 inv, f3 noi, float t_min, float t_max) {
+    const v2f_ tx = __builtin_elementwise_fma(x, v2f_{inv.x, inv.x}, v2f_{noi.x, noi.x});
+    const v2f_ ty = __builtin_elementwise_fma(y, v2f_{inv.y, inv.y}, v2f_{noi.y, noi.y});
+    const v2f_ tz = __builtin_elementwise_fma(z, v2f_{inv.z, inv.z}, v2f_{noi.z, noi.z});
+    const float t_near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)), __builtin_fmaxf(__builtin_fminf(tz.x, tz.y), t_min));
+    const float t_far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)), __builtin_fminf(__builtin_fmaxf(tz.x, tz.y), t_max));
+    return t_near <= t_far;
+}
+
+// Third traversal mode, chosen by the library for trees built with RRT_AGGREGATE_BVH_CLEAN (never by the caller): nodes are
+// tested with the ordinary interval test on their primitive boxes alone, and equal distances go to the shape that comes
+// first in SCENE order - together exactly what the reference's List aggregate returns (aggregate.rs:142-165).
+constexpr int kAabbClean = 2;
+constexpr uint32_t kLinkLeaf = 0x80000000u;  // clean trees: a child link that names a leaf's pair records directly
+
+}  // namespace rrt

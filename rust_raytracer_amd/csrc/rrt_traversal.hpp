@@ -1,0 +1,664 @@
+// Closest-hit queries: the packed pair test, the cooperative leaf phase, the node walk of deep trees, and the sifting
+// traversal of shallow trees (BVH::hit, aggregate.rs:324-401; List::hit, aggregate.rs:144-165).
+// Each function names the reference code it computes (paths relative to the reference root).
+#pragma once
+#include "rrt_primitives.hpp"
+
+namespace rrt {
+
+// ---- scene features a kernel variant is compiled for ------------------------------------------------------------------
+// The host picks the smallest variant that covers the scene, so scenes without media / image textures / bump maps do not
+// carry that code (registers, instruction cache) through the inner loop.
+enum : uint32_t {
+    F_SPHERE = 1u,  // sphere primitives (or sphere lights)
+    F_MEDIUM = 2u,  // ConstantMedium primitives and the Isotropic phase function
+    F_TEX = 4u,     // textures other than Constant (needs uv / world point in texture lookups)
+    F_BUMP = 8u,    // bump maps (needs pu, pv)
+    F_ALL = 15u
+};
+
+
+// Cost-measurement builds only (-DRRT_DUP=<bits>): the named piece is computed a second time on inputs the compiler
+// must treat as new, and the copy's result is kept alive; results are unchanged, the time difference is the piece's cost.
+#ifndef RRT_DUP
+#define RRT_DUP 0
+#endif
+#define RRT_OPAQUE(x) asm volatile("" : "+v"(x))
+#define RRT_KEEP(x) asm volatile("" ::"v"(x))
+
+#ifdef RRT_PHASE_PROFILE
+// profiling build only: per-lane node visits, per-lane pair tests, wave-level node steps, wave-level pair steps
+__device__ unsigned long long g_prof[8];  // [4..7]: sift phase (filter steps, items, dense groups, phases), counted per wave
+#endif
+
+// ---- closest hit: BVH::hit (aggregate.rs:324-401) with List::hit (aggregate.rs:144-165) in the leaves ------------
+struct Hit {
+    int slot;  // -1 = miss
+    float t;
+    float u, v, det;  // triangle hits: the values Triangle::hit computed (reused by the hit properties)
+};
+
+// One primitive of a leaf against the ray: updates `h` when it is hit closer than h.t (strict, first visited wins ties).
+template <uint32_t FEAT>
+RRT_DEV void test_slot(const DScene& sc, uint32_t s, const Ray& r, float t_min, const Rng& key, uint32_t depth, Hit& h) {
+    const cv4p cslots = sc.c_slots();
+    const v4f q0 = cslots[3 * s], q1 = cslots[3 * s + 1], q2 = cslots[3 * s + 2];
+    const uint32_t info = __float_as_uint(q1.w);
+    const uint32_t kind = RRT_INFO_KIND(info);
+    if (!(FEAT & (F_SPHERE | F_MEDIUM)) || kind == RRT_KIND_TRIANGLE) {
+        float t, u, v, det;
+        if (triangle_hit_uv(xyz(q0), xyz(q1), xyz(q2), (info & RRT_INFO_CULL) != 0, r, t_min, h.t, &t, &u, &v, &det)) {
+            h.t = t;
+            h.slot = (int)s;
+            h.u = u;
+            h.v = v;
+            h.det = det;
+        }
+    } else if ((FEAT & F_SPHERE) && kind == RRT_KIND_SPHERE) {
+        float t;
+        if (sphere_hit(sc.c_spheres() + __float_as_uint(q2.w), r, t_min, h.t, &t)) {
+            h.t = t;
+            h.slot = (int)s;
+        }
+    } else if (FEAT & F_MEDIUM) {
+        float t;
+        float xi = rng_keyed(key, depth, __float_as_uint(q0.w));
+        if (medium_hit(sc, sc.c_media() + __float_as_uint(q2.w), r, t_min, h.t, xi, &t)) {
+            h.t = t;
+            h.slot = (int)s;
+        }
+    }
+}
+
+// Two consecutive triangles of a leaf at once.  The pair record interleaves the two triangles component by component
+// (v0x_A, v0x_B, v0y_A, v0y_B, ...), so every multiply / add / subtract of Triangle::hit (shape.rs:335-372) is one packed
+// two-lane f32 instruction; each lane of a packed operation rounds exactly like the scalar one, and the two results are
+// accepted in leaf order (A, then B against the distance A may have shortened), so the outcome equals two single tests.
+typedef float v2f __attribute__((ext_vector_type(2)));
+RRT_DEV v2f splat2(float x) { return v2f{x, x}; }
+constexpr uint32_t kPairQuads = 8;  // float4 per pair record: six of primitive data, then the padded box of the two primitives (lo, hi)
+struct PairEval {
+    v2f t, u, v, det;
+    bool ok_a, ok_b;  // every acceptance test of Triangle::hit except `t < t_max`
+};
+// Returns false when both determinants were rejected (nothing else is computed then).
+RRT_DEV bool triangle_pair_eval(v4f q0, v4f q1, v4f q2, v4f q3, v4f q4, const Ray& r, float t_min, PairEval& pe) {
+    const v2f v0x = q0.xy, v0y = q0.zw, v0z = q1.xy, e1x = q1.zw, e1y = q2.xy, e1z = q2.zw, e2x = q3.xy, e2y = q3.zw, e2z = q4.xy;
+    const uint32_t info_a = __float_as_uint(q4.z), info_b = __float_as_uint(q4.w);
+    const v2f dx = splat2(r.d.x), dy = splat2(r.d.y), dz = splat2(r.d.z);
+    // p_vec = dir x edge_2 ; determinant = edge_1 . p_vec
+    const v2f px = (dy * e2z) - (dz * e2y);
+    const v2f py = (dz * e2x) - (dx * e2z);
+    const v2f pz = (dx * e2y) - (dy * e2x);
+    const v2f det = ((e1x * px) + (e1y * py)) + (e1z * pz);
+    // the cull flags are wave-uniform in the uniform leaf walk; the common all-culled pair takes a scalar branch to the plain comparisons
+    bool ok_a, ok_b;
+    if (info_a & info_b & RRT_INFO_CULL) {
+        asm volatile("");  // keeps the two arms apart (merged, they cost a per-lane select each)
+        ok_a = !(det.x < RRT_EPS);
+        ok_b = !(det.y < RRT_EPS);
+    } else {
+        ok_a = (info_a & RRT_INFO_CULL) ? !(det.x < RRT_EPS) : !(__builtin_fabsf(det.x) < RRT_EPS);
+        ok_b = (info_b & RRT_INFO_CULL) ? !(det.y < RRT_EPS) : !(__builtin_fabsf(det.y) < RRT_EPS);
+    }
+    pe.ok_a = pe.ok_b = false;
+    if (!(ok_a || ok_b)) return false;
+    // 1 / determinant for both triangles: reciprocal estimate + one fused Newton step (see exact_rcp); when the residual of
+    // either is not small (zero, denormal, huge or non-finite determinant) the whole wave takes the division instead
+    const v2f r0 = v2f{__builtin_amdgcn_rcpf(det.x), __builtin_amdgcn_rcpf(det.y)};
+    const v2f e = __builtin_elementwise_fma(-det, r0, splat2(1.0f));
+    v2f inv = __builtin_elementwise_fma(e, r0, r0);
+    if (__builtin_expect(__ballot(!(__builtin_fabsf(e.x) <= RRT_RCP_RESIDUAL) || !(__builtin_fabsf(e.y) <= RRT_RCP_RESIDUAL)) != 0ull, 0))
+        inv = v2f{1.0f / det.x, 1.0f / det.y};
+    const v2f tx = splat2(r.o.x) - v0x, ty = splat2(r.o.y) - v0y, tz = splat2(r.o.z) - v0z;
+    const v2f u = (((tx * px) + (ty * py)) + (tz * pz)) * inv;
+    // q_vec = t_vec x edge_1
+    const v2f qx = (ty * e1z) - (tz * e1y);
+    const v2f qy = (tz * e1x) - (tx * e1z);
+    const v2f qz = (tx * e1y) - (ty * e1x);
+    const v2f v = (((dx * qx) + (dy * qy)) + (dz * qz)) * inv;
+    const v2f uv = u + v;
+    const v2f t = (((e2x * qx) + (e2y * qy)) + (e2z * qz)) * inv;
+    // acceptance in the reference's order of tests; the comparisons are written so that NaNs fall the same way
+    pe.ok_a = ok_a & !(u.x < 0.0f) & !(u.x > 1.0f) & !(v.x < 0.0f) & !(uv.x > 1.0f) & (t.x > t_min);
+    pe.ok_b = ok_b & !(u.y < 0.0f) & !(u.y > 1.0f) & !(v.y < 0.0f) & !(uv.y > 1.0f) & (t.y > t_min);
+    pe.t = t;
+    pe.u = u;
+    pe.v = v;
+    pe.det = det;
+    return true;
+}
+RRT_DEV void triangle_pair_hit(v4f q0, v4f q1, v4f q2, v4f q3, v4f q4, v4f q5, const Ray& r, float t_min, Hit& h) {
+    PairEval pe;
+    if (!triangle_pair_eval(q0, q1, q2, q3, q4, r, t_min, pe)) return;
+    // A first, then B against the distance A may have shortened (leaf order)
+    const bool take_a = pe.ok_a && pe.t.x < h.t;
+    const bool take_b = pe.ok_b && pe.t.y < (take_a ? pe.t.x : h.t);
+    if (take_a) {
+        h.t = pe.t.x;
+        h.slot = (int)__float_as_uint(q5.x);
+        h.u = pe.u.x;
+        h.v = pe.v.x;
+        h.det = pe.det.x;
+    }
+    if (take_b) {
+        h.t = pe.t.y;
+        h.slot = (int)__float_as_uint(q5.y);
+        h.u = pe.u.y;
+        h.v = pe.v.y;
+        h.det = pe.det.y;
+    }
+}
+
+#define RRT_KIND_NONE 3u  // second half of an odd leaf's last pair
+
+template <uint32_t FEAT>
+RRT_DEV void test_pair(const DScene& sc, cv4p rec, const Ray& r, float t_min, const Rng& key, uint32_t depth, Hit& h) {
+    const v4f q4 = rec[4], q5 = rec[5];
+    const uint32_t kind_a = RRT_INFO_KIND(__float_as_uint(q4.z)), kind_b = RRT_INFO_KIND(__float_as_uint(q4.w));
+    if (kind_a == RRT_KIND_TRIANGLE && kind_b == RRT_KIND_TRIANGLE) {
+        triangle_pair_hit(rec[0], rec[1], rec[2], rec[3], q4, q5, r, t_min, h);
+    } else {
+        test_slot<FEAT>(sc, __float_as_uint(q5.x), r, t_min, key, depth, h);
+        if (kind_b != RRT_KIND_NONE) test_slot<FEAT>(sc, __float_as_uint(q5.y), r, t_min, key, depth, h);
+    }
+}
+
+// `stack` arguments below point at the calling lane's first entry of an LDS array laid out [entry][thread]; `stride` =
+// threads per block.  Leaves are stored as pair records (kPairQuads x float4 per two primitives); on the device a leaf
+// node's `a` is its first pair and the low bits of `b` its number of pairs.  The two primitives of a pair are in leaf
+// order (A before B) but pairs need not be: every comparison below orders candidates by (distance, slot), and slots are
+// numbered in leaf order.
+#ifdef RRT_PHASE_PROFILE
+#define RRT_COUNT(x, n) x += (n)
+#else
+#define RRT_COUNT(x, n)
+#endif
+
+// monotone map float -> uint (all non-NaN values), and back
+RRT_DEV uint32_t ord_bits(float f) {
+    const uint32_t b = __float_as_uint(f);
+    return b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+}
+RRT_DEV float ord_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ? (k ^ 0x80000000u) : ~k); }
+
+// ---- closest hit for deep trees: wave-cooperative leaves ------------------------------------------------------------
+// On a large mesh the lanes of a wave sit in different leaves of very different sizes (1 to 50+ primitives in the
+// reference's trees), and a per-lane leaf loop makes the whole wave wait for every visit.  Here a lane that reaches a leaf
+// only notes it (first pair, pair count) and pauses; when enough lanes are paused (or nobody can walk on) the wave
+// flattens all noted (lane, pair) items into one list and tests them 64 at a time, every lane taking ANY owner's pair:
+// it fetches the owner's ray through the lane crossbar, runs the ordinary pair test against the owner's closest distance,
+// and reduces with a 64-bit minimum on (distance bits, slot) in the wave's LDS area — the smallest distance wins,
+// equal distances go to the earlier slot, which is what testing the leaf front to back does.  The walk order of every
+// lane is untouched, so results are those of closest_hit.
+//
+// `coop` is this wave's LDS area: 64 x u64 keys followed by 64 x (slot, det, u, v).
+constexpr uint32_t kCoopBytesPerWave = 64 * 8 + 64 * 16;
+#ifndef RRT_COOP_LANES
+#define RRT_COOP_LANES 8
+#endif
+constexpr uint32_t kCoopLanes = RRT_COOP_LANES;  // paused lanes that trigger a cooperative leaf phase
+
+template <uint32_t FEAT, bool CLEAN>
+RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng& key, uint32_t depth, bool pending, uint32_t first_pair, uint32_t n_pairs,
+                         Hit& h, unsigned char* coop) {
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long* best = (unsigned long long*)coop;
+    v4f* payload = (v4f*)(coop + 64 * 8);
+    // inclusive prefix sum of the pair counts over the wave (lanes that are not in this call contribute nothing)
+    const uint32_t mine = pending ? n_pairs : 0u;
+    uint32_t incl = mine;
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
+        if (lane >= off) incl += up;
+    }
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    // Ties: in the reference's tree the leaf visited first wins, so what the owner already holds gets position 0; in a clean
+    // tree the shape that is first in scene order wins wherever it sits, so positions are shape numbers throughout.
+    uint32_t held = 0u;
+    if (CLEAN && h.slot >= 0) held = __float_as_uint(sc.c_slots()[3 * h.slot].w) + 1u;
+    const unsigned long long init = ((unsigned long long)ord_bits(h.t) << 32) | held;
+    best[lane] = init;
+    __threadfence_block();
+    const cv4p cpairs = sc.c_pairs();
+    for (uint32_t base = 0; base < total; base += 64u) {
+        const uint32_t item = base + lane;
+        const bool have = item < total;
+        // owner = first lane whose inclusive sum exceeds the item index
+        uint32_t lo = 0, hi = 63;
+        for (int it = 0; it < 6; ++it) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint32_t v = (uint32_t)__shfl((int)incl, (int)mid);
+            if (v <= item) lo = mid + 1; else hi = mid;
+        }
+        const int owner = (int)(have ? lo : lane);
+        const uint32_t o_incl = (uint32_t)__shfl((int)incl, owner), o_n = (uint32_t)__shfl((int)mine, owner);
+        const uint32_t o_first = (uint32_t)__shfl((int)first_pair, owner);
+        Ray ro;
+        ro.o = mk3(__shfl(r.o.x, owner), __shfl(r.o.y, owner), __shfl(r.o.z, owner));
+        ro.d = mk3(__shfl(r.d.x, owner), __shfl(r.d.y, owner), __shfl(r.d.z, owner));
+        const float o_t = __shfl(h.t, owner);
+        Rng okey = key;
+        uint32_t odepth = depth;
+        if (FEAT & F_MEDIUM) {  // the medium's distance draw is keyed by the owner's stream and depth
+            okey.s0 = (uint32_t)__shfl((int)key.s0, owner);
+            okey.s1 = (uint32_t)__shfl((int)key.s1, owner);
+            odepth = (uint32_t)__shfl((int)depth, owner);
+        }
+        Hit hh;
+        hh.slot = -1;
+        hh.t = o_t;
+        if (CLEAN && __shfl(h.slot, owner) >= 0) hh.t = ord_float(ord_bits(o_t) + 1u);  // an equal distance may still win on shape order
+        hh.u = hh.v = hh.det = 0.0f;
+        unsigned long long mykey = ~0ull;
+        if (have) {
+            const uint32_t k = item - (o_incl - o_n);  // position of the pair in its leaf
+            const cv4p rec = cpairs + kPairQuads * (o_first + k);
+            test_pair<FEAT>(sc, rec, ro, t_min, okey, odepth, hh);
+            if (hh.slot >= 0) {
+                uint32_t pos = (uint32_t)hh.slot;
+                if (CLEAN) {
+                    const v4f q5 = rec[5];  // (slot A, slot B, shape A, shape B)
+                    pos = __float_as_uint(pos == __float_as_uint(q5.x) ? q5.z : q5.w);
+                }
+                mykey = ((unsigned long long)ord_bits(hh.t) << 32) | (unsigned long long)(pos + 1u);
+                atomicMin(&best[owner], mykey);
+            }
+        }
+        __threadfence_block();
+        if (hh.slot >= 0 && best[owner] == mykey) payload[owner] = v4f{__uint_as_float((uint32_t)hh.slot), hh.det, hh.u, hh.v};
+        __threadfence_block();
+    }
+    if (pending && best[lane] != init) {
+        const v4f w = payload[lane];
+        h.t = ord_float((uint32_t)(best[lane] >> 32));
+        h.slot = (int)__float_as_uint(w.x);
+        h.det = w.y;
+        h.u = w.z;
+        h.v = w.w;
+    }
+}
+
+// One lane's walk through a deep tree, kept between steps so that callers can interleave the lanes of a wave freely.
+struct Walk {
+    uint32_t sp, cur;
+    bool running;  // has a node to visit
+    bool pending;  // stands at a leaf (first_pair, n_pairs) that the next cooperative phase tests
+    uint32_t first_pair, n_pairs;
+    f3 inv;
+    Hit h;
+};
+RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, float t_max) {
+    w.h.slot = -1;
+    w.h.t = t_max;
+    w.h.u = w.h.v = w.h.det = 0.0f;
+    w.sp = 0;
+    w.cur = sc.root_link;  // 0 for the reference's trees
+    w.pending = false;
+    w.first_pair = w.n_pairs = 0;
+    w.running = active && sc.n_nodes != 0;
+    w.inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+}
+// Visits one node (BVH::hit, aggregate.rs:343-395): an inner node that passes its test pushes one child and descends into the
+// other, a leaf that passes pauses the walk, anything else pops.
+template <int AABB_MODE>
+RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, uint32_t* stack, uint32_t stride) {
+    const cv4p cnodes = sc.c_nodes();
+    if (AABB_MODE == kAabbClean) {
+        // One fetch brings both children's boxes: only children the ray meets are ever fetched themselves, and leaves are
+        // not fetched at all (their pair range sits in the link).
+        if (w.cur & kLinkLeaf) {
+            w.pending = true;
+            w.running = false;
+            w.first_pair = w.cur & 0x0fffffffu;
+            w.n_pairs = ((w.cur >> 28) & 7u) + 1u;
+            return;
+        }
+        const v4f l0 = cnodes[4 * w.cur], l1 = cnodes[4 * w.cur + 1], r0 = cnodes[4 * w.cur + 2], r1 = cnodes[4 * w.cur + 3];
+        const bool hit_l = box_overlap(xyz(l0), xyz(l1), r.o, w.inv, t_min, w.h.t);
+        const bool hit_r = box_overlap(xyz(r0), xyz(r1), r.o, w.inv, t_min, w.h.t);
+        const uint32_t link_l = __float_as_uint(l0.w), link_r = __float_as_uint(l1.w), axis = __float_as_uint(r0.w);
+        const float dax = axis == 0u ? r.d.x : (axis == 1u ? r.d.y : r.d.z);
+        const bool left_first = !(dax < 0.0f);  // the left child holds the lower centres: nearer when the ray runs upwards
+        if (hit_l && hit_r) {
+            stack[w.sp * stride] = left_first ? link_r : link_l;
+            ++w.sp;
+            w.cur = left_first ? link_l : link_r;
+        } else if (hit_l || hit_r) {
+            w.cur = hit_l ? link_l : link_r;
+        } else if (w.sp == 0) {
+            w.running = false;
+        } else {
+            --w.sp;
+            w.cur = stack[w.sp * stride];
+        }
+        return;
+    }
+    const v4f n0 = cnodes[4 * w.cur];
+    const v4f n1 = cnodes[4 * w.cur + 1];
+    bool inside;
+    if (sc.is_list) inside = true;
+    else if (AABB_MODE == RRT_AABB_TIGHT) {
+        const v4f b0 = cnodes[4 * w.cur + 2], b1 = cnodes[4 * w.cur + 3];
+        inside = box_overlap(xyz(b0), xyz(b1), r.o, w.inv, t_min, w.h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, w.inv, t_min, w.h.t);
+    } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, w.inv, t_min, w.h.t);
+    const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
+    if (inside && !(b & RRT_LEAF_FLAG)) {
+        // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
+        const float dax = b == 0u ? r.d.x : (b == 1u ? r.d.y : r.d.z);
+        const uint32_t left = w.cur + 1u, right = a;
+        const bool left_first = dax < 0.0f;
+        stack[w.sp * stride] = left_first ? right : left;
+        ++w.sp;
+        w.cur = left_first ? left : right;
+    } else if (inside) {
+        w.pending = true;  // the leaf is tested in the next cooperative phase; the walk resumes after it
+        w.running = false;
+        w.first_pair = a;
+        w.n_pairs = b & ~RRT_LEAF_FLAG;
+    } else if (w.sp == 0) {
+        w.running = false;
+    } else {
+        --w.sp;
+        w.cur = stack[w.sp * stride];
+    }
+}
+// After the cooperative phase that tested this lane's leaf.
+RRT_DEV void walk_resume(Walk& w, uint32_t* stack, uint32_t stride) {
+    w.pending = false;
+    if (w.sp != 0) {
+        --w.sp;
+        w.cur = stack[w.sp * stride];
+        w.running = true;
+    }
+}
+
+template <int AABB_MODE, uint32_t FEAT>
+RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack,
+                             uint32_t stride, unsigned char* coop) {
+    // Must be called by all 64 lanes of the wave (the cooperative phase addresses lanes by number); lanes without a ray
+    // pass active = false and only lend a hand.
+    Walk w;
+    walk_begin(sc, w, active, r, t_max);
+#ifdef RRT_PHASE_PROFILE
+    unsigned long long prof_nodes = 0, prof_pairs = 0, prof_steps = 0, prof_leaf_steps = 0;
+#endif
+    for (;;) {
+        if (w.running) {
+            RRT_COUNT(prof_nodes, 1);
+            walk_step<AABB_MODE>(sc, w, r, t_min, stack, stride);
+            if (w.pending) RRT_COUNT(prof_pairs, w.n_pairs);
+        }
+        const unsigned long long waiting = RRT_BALLOT(w.pending), walking = RRT_BALLOT(w.running);
+#ifdef RRT_PHASE_PROFILE
+        if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_steps;
+#endif
+        if (waiting != 0ull && ((uint32_t)__popcll(waiting) >= kCoopLanes || walking == 0ull)) {
+#ifdef RRT_PHASE_PROFILE
+            if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_leaf_steps;
+#endif
+            coop_leaves<FEAT, AABB_MODE == kAabbClean>(sc, r, t_min, key, depth, w.pending, w.first_pair, w.n_pairs, w.h, coop);
+            if (w.pending) walk_resume(w, stack, stride);
+        } else if (waiting == 0ull && walking == 0ull) {
+            break;
+        }
+    }
+#ifdef RRT_PHASE_PROFILE
+    atomicAdd(&g_prof[0], prof_nodes);
+    atomicAdd(&g_prof[1], prof_pairs);
+    atomicAdd(&g_prof[2], prof_steps);
+    atomicAdd(&g_prof[3], prof_leaf_steps);
+#endif
+    return w.h;
+}
+
+// Recomputes (u, v, det) the way Triangle::get_hit_properties does (shape.rs:384-400) for callers without a Hit.
+RRT_DEV void triangle_uvdet(f3 v0, f3 e1, f3 e2, const Ray& r, float* u, float* v, float* det) {
+    f3 p_vec = cross3(r.d, e2);
+    float d = dot3(e1, p_vec);
+    float inv_det = 1.0f / d;
+    f3 t_vec = r.o - v0;
+    *u = dot3(t_vec, p_vec) * inv_det;
+    f3 q_vec = cross3(t_vec, e1);
+    *v = dot3(r.d, q_vec) * inv_det;
+    *det = d;
+}
+// ---- closest hit for shallow trees: sift, then test densely ------------------------------------------------------------
+// The reference's trees for small scenes are one or a few big leaves (its SAH rarely splits them), so every ray would run
+// the full test against every primitive.  Here a lane that reaches a leaf pauses; once no lane is walking, the wave
+//  1. sifts: each paused lane tests its ray against the padded box of every pair of its leaf (wave-uniform pair index, box
+//     in scalar registers) and appends an item (pair, lane) to a list in LDS for every box its ray overlaps.  A pair whose
+//     box the ray misses within (t_min, closest so far] holds nothing the ray can hit, so nothing is lost;
+//  2. tests densely: the items are handed out 64 at a time, any lane taking any owner's item: it fetches the owner's ray
+//     through the lane crossbar, runs the exact pair test and posts (distance, slot) with a 64-bit LDS
+//     minimum - the smallest distance wins and equal distances go to the earlier primitive, which is what testing the
+//     leaf front to back with a strict comparison does (aggregate.rs:144-165).
+// The walk order of every lane is the reference's, so results equal closest_hit.
+// `area` is this wave's LDS: 64 x u64 keys, then kSiftCap x u32 items (then 64 x kHarvestLights floats when harvesting).
+//
+// HARVEST (single-leaf scenes with a few lights).  After a diffuse bounce the reference evaluates the light mixture's
+// density for the scattered ray, which costs one more intersection test per light (Shape::pdf, shape.rs:141-147, 441-458)
+// - against the very primitives the NEXT closest-hit query of that same ray tests anyway.  With HARVEST the query also
+// reports, per light, the distance at which the ray meets the light's own primitive (any distance in (t_min, t_max), whether
+// or not something nearer hides it, and whether or not the leaf's box test let the ray in: Shape::pdf asks the shape, not
+// the tree), and the caller finishes the previous bounce's throughput from that.  Same tests, same numbers, run once.
+constexpr uint32_t kSiftCap = 512;
+constexpr uint32_t kHarvestLights = 4;
+constexpr uint32_t kSiftBytesPerWave = 64 * 8 + kSiftCap * 4;
+constexpr uint32_t kHarvestBytesPerWave = 64 * kHarvestLights * 4;
+#define RRT_PAIR_LIGHT(info) (((info) >> 24) & 15u)  // device-only bits of a pair record's info words: light number + 1
+
+template <uint32_t FEAT, bool HARVEST>
+RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, const uint32_t* items, uint32_t n_items,
+                        unsigned long long* best) {
+    constexpr uint32_t kLaneShift = HARVEST ? 7 : 6;  // HARVEST items carry one more bit: the owner only wants its lights
+    float* light_t = (float*)((unsigned char*)best + kSiftBytesPerWave);
+    const uint32_t lane = threadIdx.x & 63u;
+    const cv4p cpairs = sc.c_pairs();
+    __threadfence_block();
+    for (uint32_t base = 0; base < n_items; base += 64u) {
+        const uint32_t idx = base + lane;
+        const bool have = idx < n_items;
+        const uint32_t item = have ? items[idx] : lane;
+        const int owner = (int)(item & 63u);
+        const uint32_t pair = item >> kLaneShift;
+        const bool lights_only = HARVEST && (item & 64u) != 0u;
+        Ray ro;
+        ro.o = mk3(__shfl(r.o.x, owner), __shfl(r.o.y, owner), __shfl(r.o.z, owner));
+        ro.d = mk3(__shfl(r.d.x, owner), __shfl(r.d.y, owner), __shfl(r.d.z, owner));
+        Rng okey = key;
+        uint32_t odepth = depth;
+        if (FEAT & F_MEDIUM) {  // the medium's distance draw is keyed by the owner's stream and depth
+            okey.s0 = (uint32_t)__shfl((int)key.s0, owner);
+            okey.s1 = (uint32_t)__shfl((int)key.s1, owner);
+            odepth = (uint32_t)__shfl((int)depth, owner);
+        }
+        if (have) {
+            const cv4p rec = cpairs + kPairQuads * pair;
+            const v4f q4 = rec[4];
+            const uint32_t kind_a = RRT_INFO_KIND(__float_as_uint(q4.z)), kind_b = RRT_INFO_KIND(__float_as_uint(q4.w));
+            const v4f q5 = rec[5];
+            const uint32_t light_a = HARVEST ? RRT_PAIR_LIGHT(__float_as_uint(q4.z)) : 0u, light_b = HARVEST ? RRT_PAIR_LIGHT(__float_as_uint(q4.w)) : 0u;
+            bool found = false, second = false, det_neg = false;
+            float t_found = t_max;
+            if (kind_a == RRT_KIND_TRIANGLE && kind_b == RRT_KIND_TRIANGLE) {
+                PairEval pe;
+                if (triangle_pair_eval(rec[0], rec[1], rec[2], rec[3], q4, ro, t_min, pe)) {
+                    const bool ok_a = pe.ok_a && pe.t.x < t_max, ok_b = pe.ok_b && pe.t.y < t_max;
+                    if (HARVEST && (light_a | light_b) != 0u) {  // Triangle::pdf's own hit test (shape.rs:446): this one
+                        if (light_a != 0u && ok_a) light_t[(uint32_t)owner * kHarvestLights + light_a - 1u] = pe.t.x;
+                        if (light_b != 0u && ok_b) light_t[(uint32_t)owner * kHarvestLights + light_b - 1u] = pe.t.y;
+                    }
+                    second = ok_b && !(ok_a && !(pe.t.y < pe.t.x));  // A keeps an equal distance (leaf order)
+                    found = ok_a || ok_b;
+                    t_found = second ? pe.t.y : pe.t.x;
+                    det_neg = (second ? pe.det.y : pe.det.x) < 0.0f;
+                }
+            } else {
+                Hit hh;
+                hh.slot = -1;
+                hh.t = t_max;
+                hh.u = hh.v = hh.det = 0.0f;
+                test_slot<FEAT>(sc, __float_as_uint(q5.x), ro, t_min, okey, odepth, hh);
+                if (HARVEST && light_a != 0u && hh.slot >= 0) light_t[(uint32_t)owner * kHarvestLights + light_a - 1u] = hh.t;  // Sphere::pdf, shape.rs:142
+                if (kind_b != RRT_KIND_NONE) {
+                    const int before = hh.slot;
+                    const float t_before = hh.t;
+                    test_slot<FEAT>(sc, __float_as_uint(q5.y), ro, t_min, okey, odepth, hh);
+                    second = hh.slot >= 0 && (before < 0 || hh.t < t_before);
+                }
+                found = hh.slot >= 0;
+                t_found = hh.t;
+                det_neg = hh.det < 0.0f;
+            }
+            if (found && !lights_only) {
+                const uint32_t slot = __float_as_uint(second ? q5.y : q5.x);
+                const uint32_t low = ((slot + 1u) << 1) | (det_neg ? 1u : 0u);
+                atomicMin(&best[owner], ((unsigned long long)ord_bits(t_found) << 32) | (unsigned long long)low);
+            }
+        }
+    }
+    __threadfence_block();
+}
+
+template <int AABB_MODE, uint32_t FEAT, bool HARVEST = false>
+RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack,
+                             uint32_t stride, unsigned char* area, float* harvest = nullptr) {
+    // Must be called by all 64 lanes of the wave (the dense phase addresses lanes by number); lanes without a ray pass
+    // active = false and only lend a hand.  HARVEST: the tree is a single leaf; harvest[i] receives the distance at which the
+    // ray meets light i's primitive, or -1.
+    Hit h;
+    h.slot = -1;
+    h.t = t_max;
+    h.u = h.v = h.det = 0.0f;
+    if (sc.n_nodes == 0) return h;
+    const uint32_t lane = threadIdx.x & 63u;
+    unsigned long long* best = (unsigned long long*)area;
+    uint32_t* items = (uint32_t*)(area + 64 * 8);
+    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    // for the pair boxes: plane * finv + noi (see pair_box_overlap); an axis whose product origin * inv is not finite (zero or
+    // denormal direction component) gets NaN, which the interval test ignores: that axis then constrains nothing
+    f3 finv = inv, noi = mk3(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
+    if (!(__builtin_fabsf(noi.x) < __builtin_inff())) { finv.x = 0.0f; noi.x = __builtin_nanf(""); }
+    if (!(__builtin_fabsf(noi.y) < __builtin_inff())) { finv.y = 0.0f; noi.y = __builtin_nanf(""); }
+    if (!(__builtin_fabsf(noi.z) < __builtin_inff())) { finv.z = 0.0f; noi.z = __builtin_nanf(""); }
+#ifdef RRT_PHASE_PROFILE
+    unsigned long long prof_filter = 0, prof_items = 0, prof_groups = 0, prof_phases = 0;
+#endif
+    const cv4p cnodes = sc.c_nodes();
+    const cv4p cpairs = sc.c_pairs();
+    uint32_t sp = 0, cur = 0;
+    bool running = active, pending = false;
+    bool lights_only = false;  // HARVEST: the leaf's box test failed, so only the lights' own primitives are of interest
+    uint32_t first_pair = 0, n_pairs = 0;
+    float* light_t = (float*)(area + kSiftBytesPerWave);
+    if (HARVEST)
+        for (uint32_t i = 0; i < kHarvestLights; ++i) harvest[i] = -1.0f;
+    for (;;) {
+        if (running) {
+            const v4f n0 = cnodes[4 * cur];
+            const v4f n1 = cnodes[4 * cur + 1];
+            bool inside;
+            if (sc.is_list) inside = true;
+            else if (AABB_MODE == RRT_AABB_TIGHT) {
+                const v4f b0 = cnodes[4 * cur + 2], b1 = cnodes[4 * cur + 3];
+                inside = box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
+            } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
+            const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
+            if (inside && !(b & RRT_LEAF_FLAG)) {
+                // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
+                const float dax = b == 0u ? r.d.x : (b == 1u ? r.d.y : r.d.z);
+                const uint32_t left = cur + 1u, right = a;
+                const bool left_first = dax < 0.0f;
+                stack[sp * stride] = left_first ? right : left;
+                ++sp;
+                cur = left_first ? left : right;
+            } else if (inside || HARVEST) {
+                pending = true;  // the leaf is tested in the next sift phase; the walk resumes after it
+                running = false;
+                lights_only = !inside;
+                first_pair = a;
+                n_pairs = b & ~RRT_LEAF_FLAG;
+            } else if (sp == 0) {
+                running = false;
+            } else {
+                --sp;
+                cur = stack[sp * stride];
+            }
+        }
+        if (RRT_BALLOT(running) != 0ull) continue;
+        const unsigned long long waiting = RRT_BALLOT(pending);
+        if (waiting == 0ull) break;
+        best[lane] = (unsigned long long)ord_bits(h.t) << 32;  // position 0: what the owner already holds wins ties
+        if (HARVEST)
+            for (uint32_t i = 0; i < kHarvestLights; ++i) light_t[lane * kHarvestLights + i] = -1.0f;
+        uint32_t n_items = 0;
+        unsigned long long todo = waiting;
+        while (todo != 0ull) {
+            // the paused lanes are grouped by leaf (one group for the single-leaf trees of the small scenes)
+            const int leader = __ffsll((long long)todo) - 1;
+            const uint32_t leaf_first = (uint32_t)__builtin_amdgcn_readlane((int)first_pair, leader);
+            const uint32_t leaf_pairs = (uint32_t)__builtin_amdgcn_readlane((int)n_pairs, leader);
+            const bool mine = pending && first_pair == leaf_first;
+            for (uint32_t k = 0; k < leaf_pairs; ++k) {
+                const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
+                const v4f bx = rec[6], bz = rec[7];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, -, -)
+                bool pass = mine && pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, h.t);
+                if (HARVEST && __float_as_uint(bz.z) == 0u) pass = pass && !lights_only;  // bz.z: the pair holds a light's primitive
+                const unsigned long long bal = RRT_BALLOT(pass);
+                if (pass) {
+                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                    if (HARVEST) items[n_items + rank] = ((leaf_first + k) << 7) | (lights_only ? 64u : 0u) | lane;
+                    else items[n_items + rank] = ((leaf_first + k) << 6) | lane;
+                }
+                n_items += (uint32_t)__popcll(bal);
+                RRT_COUNT(prof_filter, 1);
+                if (n_items > kSiftCap - 64u) {
+                    RRT_COUNT(prof_items, n_items);
+                    RRT_COUNT(prof_groups, (n_items + 63u) / 64u);
+                    sift_flush<FEAT, HARVEST>(sc, r, t_min, t_max, key, depth, items, n_items, best);
+                    n_items = 0;
+                }
+            }
+            todo &= ~RRT_BALLOT(mine);
+        }
+        RRT_COUNT(prof_items, n_items);
+        RRT_COUNT(prof_groups, (n_items + 63u) / 64u);
+        RRT_COUNT(prof_phases, 1);
+        sift_flush<FEAT, HARVEST>(sc, r, t_min, t_max, key, depth, items, n_items, best);
+        if (pending) {
+            if (HARVEST)
+                for (uint32_t i = 0; i < kHarvestLights; ++i) harvest[i] = light_t[lane * kHarvestLights + i];
+            const unsigned long long w = best[lane];
+            const uint32_t low = (uint32_t)w;
+            if (low != 0u) {
+                h.t = ord_float((uint32_t)(w >> 32));
+                h.slot = (int)((low >> 1) - 1u);
+                h.det = (low & 1u) ? -1.0f : 1.0f;  // only the sign is used (by the hit properties)
+            }
+            pending = false;
+            if (sp != 0) {
+                --sp;
+                cur = stack[sp * stride];
+                running = true;
+            }
+        }
+    }
+#ifdef RRT_PHASE_PROFILE
+    if (lane == 0) {  // wave-level counts
+        atomicAdd(&g_prof[4], prof_filter);
+        atomicAdd(&g_prof[5], prof_items);
+        atomicAdd(&g_prof[6], prof_groups);
+        atomicAdd(&g_prof[7], prof_phases);
+    }
+#endif
+    if ((FEAT & (F_TEX | F_BUMP)) && h.slot >= 0) {
+        // Triangle::get_hit_properties recomputes the barycentrics from the ray (shape.rs:384-400); so does this path
+        const cv4p cslots = sc.c_slots();
+        const v4f q0 = cslots[3 * h.slot], q1 = cslots[3 * h.slot + 1], q2 = cslots[3 * h.slot + 2];
+        if (RRT_INFO_KIND(__float_as_uint(q1.w)) == RRT_KIND_TRIANGLE) triangle_uvdet(xyz(q0), xyz(q1), xyz(q2), r, &h.u, &h.v, &h.det);
+    }
+    return h;
+}
+
+}  // namespace rrt
