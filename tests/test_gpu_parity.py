@@ -340,6 +340,21 @@ def test_render_is_independent_of_the_pass_split_and_of_odd_sizes(gpu):
     assert one.shape == (1, 1, 3) and np.isfinite(one).all()
 
 
+@pytest.mark.parametrize("aggregate", ["BVH", "List", "BVH_GPU", "BVH_CLEAN"])
+def test_empty_scene(gpu, aggregate):
+    """No shapes at all (an empty BVH has no nodes, aggregate.rs:339-341): every path is one ray that sees the background."""
+    hs = rrt.HostScene.new()
+    hs.add_material(0, hs.add_texture(0, 0.5, 0.5, 0.5))
+    hs.set_camera((0, 0, 1), (0, 0, 0), (0, 1, 0), 60, 1.5, 0.0, 1.0)
+    hs.set_logistics(24, 16, 3)
+    hs.finalize(aggregate)
+    sc = rrt.Scene(hs)
+    img, st = sc.render(seed=1, background=rrt.BG_SKY)
+    assert st["rays"] == st["paths"] == 24 * 16 * 3 and np.isfinite(img).all() and img.min() > 1.0
+    p, _ = sc.hit(np.zeros((5, 3), np.float32), np.ones((5, 3), np.float32))
+    assert (p == -1).all()
+
+
 def test_fast_reciprocal_is_exact_for_every_float(gpu):
     assert rrt.selftest_reciprocal() == 0
 
