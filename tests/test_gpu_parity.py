@@ -135,6 +135,21 @@ def test_render_bit_exact_on_a_million_paths(gpu, name, bg):
     assert st["rays"] == int(st_ref[0]) and st["paths"] == W * H * spp
 
 
+def test_large_odd_frame_and_ragged_batches(gpu):
+    """A frame of 1003 x 701 pixels (no multiple of the 8x8 wave tile or of the 32x32 sharding tile) of the textured, bump-mapped
+    globe; ray batches of 0, 1, 63, 64, 65 and 1000 rays."""
+    W, H, spp = 1003, 701, 2
+    o, g = both("Globe.json", resolution_x=W, resolution_y=H, samples=spp)
+    ref, st_ref = o.render(W, H, spp, seed=23, bg=rrt.BG_SKY, threads=min(16, len(__import__("os").sched_getaffinity(0))))
+    img, st = g.render(seed=23, background=rrt.BG_SKY)
+    assert np.array_equal(bits(img), bits(ref)) and st["rays"] == int(st_ref[0]) and st["paths"] == W * H * spp
+    ro, rd = raygen.ray_batch(o, 64, 64, n_random=300, seed=1)
+    for n in (0, 1, 63, 64, 65, 1000):
+        p_ref, t_ref = o.intersect(ro[:n], rd[:n]) if n else (np.zeros(0, np.int32), np.zeros(0, np.float32))
+        p, t = g.hit(ro[:n], rd[:n])
+        assert np.array_equal(p, p_ref) and np.array_equal(bits(t), bits(t_ref))
+
+
 def test_render_sample_ranges_and_tiles(gpu):
     """first_sample continues the per-pixel stream; interleaved tiles reproduce the full frame bit for bit."""
     o, g = both("Cornell_Box_With_Sphere.json", resolution_x=80, resolution_y=72, samples=8)
