@@ -642,7 +642,7 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     if (rc) return rc;
     rrt_scene* s = new rrt_scene();
     HIP_TRY(hipGetDevice(&s->device));
-    uint32_t clean_depth = 0;  // clean trees: deepest inner node of the device tree (sizes the traversal stack)
+    uint32_t clean_depth = 0;  // clean trees: most stack entries a walk can have pending (sizes the traversal stack)
 #define UP(field, src, count)                                                        \
     do {                                                                             \
         rc = upload(src, count, (const void**)&s->d.field, &s->owned);               \
@@ -761,9 +761,12 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         }
         const std::vector<float> tb = tight_boxes(desc);
         if (clean) {
-            // Inner nodes only, 64 bytes each, holding BOTH children's primitive boxes and links (see walk_step): a link is an
-            // inner node's number or kLinkLeaf | (pairs - 1) << 28 | first pair.  A leaf of more than 8 pair records (shapes
-            // the sweep would not separate) is hung under extra inner nodes that halve its range.
+            // Inner nodes only, 128 bytes each, with up to FOUR children (see walk_step): quads 0..5 hold the children's
+            // primitive boxes plane by plane (lo.x of the four children, hi.x, lo.y, hi.y, lo.z, hi.z), quad 6 their links: an
+            // inner node's number, kLinkLeaf | (pairs - 1) << 28 | first pair, or kLinkNone for an unused place.  A node
+            // starts from the sweep's two children and replaces the child with the largest box by that child's own two
+            // until it has four; a leaf of more than 8 pair records (shapes the sweep would not separate) is split by
+            // halving its range.
             std::vector<float> rec;
             auto pair_range_box = [&](uint32_t first, uint32_t count, float* b) {  // pair boxes are stored (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z)
                 const float inf = std::numeric_limits<float>::infinity();
@@ -777,79 +780,87 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                     }
                 }
             };
-            struct Pending { uint32_t node; bool is_range; uint32_t first, count; uint32_t parent, depth; };
-            auto new_inner = [&]() {
-                rec.resize(rec.size() + 16, 0.0f);
-                return (uint32_t)(rec.size() / 16 - 1);
+            struct Child { uint32_t node; bool is_range; uint32_t first, count; float box[8]; };
+            auto child_of_node = [&](uint32_t node) {
+                const rrt_node& c = dn[node];
+                const bool leaf = (c.b & RRT_LEAF_FLAG) != 0;
+                Child ch = {node, leaf, leaf ? c.a : 0u, leaf ? (c.b & ~RRT_LEAF_FLAG) : 0u, {}};
+                std::memcpy(ch.box, &tb[(size_t)node * 8], 32);
+                return ch;
             };
-            auto set_child = [&](uint32_t parent, uint32_t side, const float* box, uint32_t link) {
-                float* r = &rec[(size_t)parent * 16 + (side ? 8 : 0)];
-                std::memcpy(r, box, 12);
-                std::memcpy(r + 4, box + 4, 12);
-                std::memcpy(&rec[(size_t)parent * 16 + (side ? 7 : 3)], &link, 4);  // left link in quad 0, right link in quad 1
-            };
-            // links of quad 1.w (right link) and quad 2.w (axis) share no slot with the right box: quad 2 = (right lo, axis), quad 3 = (right hi, -)
-            std::vector<Pending> todo;
-            uint32_t root_link = 0;
-            auto link_of = [&](uint32_t node, bool is_range, uint32_t first, uint32_t count, uint32_t* out_link) -> bool {
-                // returns true when the child is a leaf small enough for a direct link
-                if (!is_range) {
-                    const rrt_node& n = dn[node];
-                    if (!(n.b & RRT_LEAF_FLAG)) return false;
-                    first = n.a;
-                    count = n.b & ~RRT_LEAF_FLAG;
-                }
-                if (count > 8 || first > 0x0fffffffu) return false;
-                *out_link = kLinkLeaf | ((count - 1u) << 28) | first;
+            auto link_of = [&](const Child& c, uint32_t* out_link) -> bool {  // true when the child is a leaf small enough for a direct link
+                if (!c.is_range || c.count > 8) return false;
+                *out_link = kLinkLeaf | ((c.count - 1u) << 28) | c.first;
                 return true;
             };
-            if ((uint64_t)pairs.size() / (4 * kPairQuads) > 0x0fffffffull) {
+            auto split = [&](const Child& c, Child* out) {
+                if (c.is_range) {  // an oversized leaf: halve its pair range
+                    const uint32_t half = c.count / 2;
+                    out[0] = {0u, true, c.first, half, {}};
+                    out[1] = {0u, true, c.first + half, c.count - half, {}};
+                    pair_range_box(out[0].first, out[0].count, out[0].box);
+                    pair_range_box(out[1].first, out[1].count, out[1].box);
+                } else {
+                    out[0] = child_of_node(c.node + 1u);
+                    out[1] = child_of_node(dn[c.node].a);
+                }
+            };
+            auto new_inner = [&]() {
+                const float inf = std::numeric_limits<float>::infinity();
+                const size_t at = rec.size();
+                rec.resize(at + 32, 0.0f);
+                for (int k = 0; k < 24; ++k) rec[at + k] = inf;  // a box no ray meets
+                for (int k = 24; k < 28; ++k) rec[at + k] = put_u(kLinkNone);
+                return (uint32_t)(at / 32);
+            };
+            if ((uint64_t)pairs.size() / (4 * kPairQuads) >= 0x0fffffffull) {  // keeps every leaf link apart from kLinkNone
                 rrt_scene_destroy(s);
-                return rrt_set_error(RRT_ERR_LIMIT, "clean tree: more than 2^28 pair records");
+                return rrt_set_error(RRT_ERR_LIMIT, "clean tree: more than 2^28 - 2 pair records");
             }
+            struct Pending { Child c; uint32_t self, above; };  // above: stack entries that can be pending when the walk reaches this node
+            std::vector<Pending> todo;
+            uint32_t root_link = 0;
             if (!dn.empty()) {
+                const Child root = child_of_node(0);
                 uint32_t link;
-                if (link_of(0, false, 0, 0, &link)) root_link = link;
+                if (link_of(root, &link)) root_link = link;
                 else {
                     root_link = new_inner();
-                    todo.push_back({0u, (dn[0].b & RRT_LEAF_FLAG) != 0, dn[0].a, dn[0].b & ~RRT_LEAF_FLAG, root_link, 1u});
+                    todo.push_back({root, root_link, 0u});
                 }
             }
-            // each entry: fill inner node `parent` (already allocated) from tree node `node` (or from a pair range)
             while (!todo.empty()) {
                 const Pending it = todo.back();
                 todo.pop_back();
-                const uint32_t self = it.parent;
-                if (it.depth > clean_depth) clean_depth = it.depth;
-                uint32_t axis = 0;
-                struct Child { uint32_t node; bool is_range; uint32_t first, count; float box[8]; } ch[2];
-                if (it.is_range) {  // an oversized leaf: halve its pair range
-                    const uint32_t half = it.count / 2;
-                    ch[0] = {0u, true, it.first, half, {}};
-                    ch[1] = {0u, true, it.first + half, it.count - half, {}};
-                    pair_range_box(ch[0].first, ch[0].count, ch[0].box);
-                    pair_range_box(ch[1].first, ch[1].count, ch[1].box);
-                } else {
-                    const rrt_node& n = dn[it.node];
-                    axis = n.b;
-                    const uint32_t kids[2] = {it.node + 1u, n.a};
-                    for (int k = 0; k < 2; ++k) {
-                        const rrt_node& c = dn[kids[k]];
-                        const bool leaf = (c.b & RRT_LEAF_FLAG) != 0;
-                        ch[k] = {kids[k], false, leaf ? c.a : 0u, leaf ? (c.b & ~RRT_LEAF_FLAG) : 0u, {}};
-                        std::memcpy(ch[k].box, &tb[(size_t)kids[k] * 8], 32);
-                    }
-                }
-                for (uint32_t k = 0; k < 2; ++k) {
+                Child kids[5];
+                uint32_t n_kids = 2;
+                split(it.c, kids);
+                while (n_kids < 4) {
+                    int widest = -1;
                     uint32_t link;
-                    const bool leaf_node = !ch[k].is_range && (dn[ch[k].node].b & RRT_LEAF_FLAG) != 0;
-                    if (!link_of(ch[k].node, ch[k].is_range, ch[k].first, ch[k].count, &link)) {
-                        link = new_inner();
-                        todo.push_back({ch[k].node, ch[k].is_range || leaf_node, ch[k].first, ch[k].count, link, it.depth + 1u});
-                    }
-                    set_child(self, k, ch[k].box, link);
+                    for (uint32_t k = 0; k < n_kids; ++k)
+                        if (!link_of(kids[k], &link) && (widest < 0 || half_area(kids[k].box) > half_area(kids[widest].box))) widest = (int)k;
+                    if (widest < 0) break;
+                    Child two[2];
+                    split(kids[widest], two);
+                    kids[widest] = two[0];
+                    kids[n_kids++] = two[1];
                 }
-                std::memcpy(&rec[(size_t)self * 16 + 11], &axis, 4);
+                const uint32_t pending_here = it.above + n_kids - 1u;  // the walk pushes every child it meets but the nearest
+                if (pending_here > clean_depth) clean_depth = pending_here;
+                for (uint32_t k = 0; k < n_kids; ++k) {
+                    uint32_t link;
+                    if (!link_of(kids[k], &link)) {
+                        link = new_inner();
+                        todo.push_back({kids[k], link, pending_here});
+                    }
+                    float* r = &rec[(size_t)it.self * 32];
+                    for (int c = 0; c < 3; ++c) {
+                        r[8 * c + k] = kids[k].box[c];
+                        r[8 * c + 4 + k] = kids[k].box[4 + c];
+                    }
+                    r[24 + k] = put_u(link);
+                }
             }
             s->d.root_link = root_link;
             if (clean_depth + 1u > kMaxStackDepth) {

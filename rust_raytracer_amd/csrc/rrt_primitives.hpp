@@ -195,5 +195,17 @@ RRT_DEV bool pair_box_overlap(v2f_ x, v2f_ y, v2f_ z, f3 inv, f3 noi, float t_mi
 // first in SCENE order - together exactly what the reference's List aggregate returns (aggregate.rs:142-165).
 constexpr int kAabbClean = 2;
 constexpr uint32_t kLinkLeaf = 0x80000000u;  // clean trees: a child link that names a leaf's pair records directly
+constexpr uint32_t kLinkNone = 0xffffffffu;  // clean trees: an unused child place of a four-wide node
+
+// box_overlap() that also reports where the span starts (the order in which a four-wide node's children are visited).
+RRT_DEV bool box_span(float lox, float hix, float loy, float hiy, float loz, float hiz, f3 o, f3 inv, float t_min, float t_max, float* entry) {
+    const float ax = (lox - o.x) * inv.x, bx = (hix - o.x) * inv.x;
+    const float ay = (loy - o.y) * inv.y, by = (hiy - o.y) * inv.y;
+    const float az = (loz - o.z) * inv.z, bz = (hiz - o.z) * inv.z;
+    const float t_near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(ax, bx), __builtin_fminf(ay, by)), __builtin_fmaxf(__builtin_fminf(az, bz), t_min));
+    const float t_far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(ax, bx), __builtin_fmaxf(ay, by)), __builtin_fminf(__builtin_fmaxf(az, bz), t_max));
+    *entry = t_near;
+    return t_near <= t_far;
+}
 
 }  // namespace rrt

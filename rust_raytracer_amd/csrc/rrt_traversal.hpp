@@ -305,8 +305,9 @@ template <int AABB_MODE>
 RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, uint32_t* stack, uint32_t stride) {
     const cv4p cnodes = sc.c_nodes();
     if (AABB_MODE == kAabbClean) {
-        // One fetch brings both children's boxes: only children the ray meets are ever fetched themselves, and leaves are
-        // not fetched at all (their pair range sits in the link).
+        // One 128-byte fetch brings the boxes of up to four children: only children the ray meets are ever fetched themselves,
+        // and leaves are not fetched at all (their pair range sits in the link).  Children are visited nearest entry first;
+        // the result does not depend on the order (ties go by scene order, see coop_leaves).
         if (w.cur & kLinkLeaf) {
             w.pending = true;
             w.running = false;
@@ -314,24 +315,41 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, uin
             w.n_pairs = ((w.cur >> 28) & 7u) + 1u;
             return;
         }
-        const v4f l0 = cnodes[4 * w.cur], l1 = cnodes[4 * w.cur + 1], r0 = cnodes[4 * w.cur + 2], r1 = cnodes[4 * w.cur + 3];
-        const bool hit_l = box_overlap(xyz(l0), xyz(l1), r.o, w.inv, t_min, w.h.t);
-        const bool hit_r = box_overlap(xyz(r0), xyz(r1), r.o, w.inv, t_min, w.h.t);
-        const uint32_t link_l = __float_as_uint(l0.w), link_r = __float_as_uint(l1.w), axis = __float_as_uint(r0.w);
-        const float dax = axis == 0u ? r.d.x : (axis == 1u ? r.d.y : r.d.z);
-        const bool left_first = !(dax < 0.0f);  // the left child holds the lower centres: nearer when the ray runs upwards
-        if (hit_l && hit_r) {
-            stack[w.sp * stride] = left_first ? link_r : link_l;
-            ++w.sp;
-            w.cur = left_first ? link_l : link_r;
-        } else if (hit_l || hit_r) {
-            w.cur = hit_l ? link_l : link_r;
-        } else if (w.sp == 0) {
-            w.running = false;
-        } else {
-            --w.sp;
-            w.cur = stack[w.sp * stride];
+        const uint32_t base = 8u * w.cur;
+        const v4f lox = cnodes[base], hix = cnodes[base + 1], loy = cnodes[base + 2], hiy = cnodes[base + 3], loz = cnodes[base + 4],
+                  hiz = cnodes[base + 5], links = cnodes[base + 6];
+        unsigned long long key[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float entry;
+            const uint32_t link = __float_as_uint(links[k]);
+            const bool met = box_span(lox[k], hix[k], loy[k], hiy[k], loz[k], hiz[k], r.o, w.inv, t_min, w.h.t, &entry) && link != kLinkNone;
+            key[k] = met ? (((unsigned long long)ord_bits(entry) << 32) | link) : ~0ull;
         }
+#define RRT_ORDER(a, b)                                   \
+    {                                                     \
+        const unsigned long long lo_ = a < b ? a : b;     \
+        b = a < b ? b : a;                                \
+        a = lo_;                                          \
+    }
+        RRT_ORDER(key[0], key[1]) RRT_ORDER(key[2], key[3]) RRT_ORDER(key[0], key[2]) RRT_ORDER(key[1], key[3]) RRT_ORDER(key[1], key[2])
+#undef RRT_ORDER
+        if (key[0] == ~0ull) {
+            if (w.sp == 0) {
+                w.running = false;
+            } else {
+                --w.sp;
+                w.cur = stack[w.sp * stride];
+            }
+            return;
+        }
+        w.cur = (uint32_t)key[0];
+#pragma unroll
+        for (int k = 3; k >= 1; --k)
+            if (key[k] != ~0ull) {
+                stack[w.sp * stride] = (uint32_t)key[k];
+                ++w.sp;
+            }
         return;
     }
     const v4f n0 = cnodes[4 * w.cur];
