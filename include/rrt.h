@@ -283,6 +283,12 @@ int rrt_render_device(rrt_scene*, const rrt_render_params* params, float* d_rgb_
  * does not depend on the split.  No counterpart in the reference (its colours vector, main.rs:115-121, is per pixel). */
 int rrt_scene_set_staging_limit(rrt_scene*, uint64_t bytes);
 
+/* Deep trees (more than 16 nodes, clean trees): how many of a ray's pending-node stack entries the render kernel keeps in
+ * LDS (1..64; 0 restores the default of 34, the most that still lets a compute unit hold 16 waves); deeper entries live
+ * in the lane's private memory.  Changes speed only, never results.  No counterpart in the reference (its stack is a
+ * Vec on the host heap, aggregate.rs:352). */
+int rrt_scene_set_lds_stack(rrt_scene*, uint32_t entries);
+
 /* Per-kernel timing (≙ the reference's only instrumentation, the wall clock of main.rs:64, 191, split by kernel).
  * While enabled, every render pass records device events around its trace and accumulate kernels on the caller's
  * stream; rrt_scene_kernel_times waits for the recorded passes, returns the summed durations in milliseconds and the

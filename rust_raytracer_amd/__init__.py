@@ -130,6 +130,7 @@ def lib():
     L.rrt_render.argtypes = [vp, C.POINTER(_RenderParams), vp, C.POINTER(_Stats)]
     L.rrt_render_device.argtypes = [vp, C.POINTER(_RenderParams), vp, vp, vp]
     L.rrt_scene_set_staging_limit.argtypes = [vp, C.c_uint64]
+    L.rrt_scene_set_lds_stack.argtypes = [vp, C.c_uint32]
     L.rrt_scene_set_timing.argtypes = [vp, C.c_int]
     L.rrt_scene_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.rrt_resolve_rgb8.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
@@ -338,6 +339,10 @@ class Scene:
     def set_staging_limit(self, nbytes):
         """Memory budget of the per-sample radiance staging buffer (0 = the 16 GiB default)."""
         _check(lib().rrt_scene_set_staging_limit(self._h, nbytes))
+
+    def set_lds_stack(self, entries):
+        """Deep trees: stack entries per ray kept in LDS by the render kernel (0 = the default); speed only, same results."""
+        _check(lib().rrt_scene_set_lds_stack(self._h, entries))
 
     def set_timing(self, enable=True):
         """Record device events around the trace and accumulate kernels of every following render pass."""

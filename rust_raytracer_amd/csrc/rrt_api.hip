@@ -22,7 +22,8 @@ constexpr int kTraceBlock = 64;          // k_trace: one wave per block, the uni
 #define RRT_CHUNK 64
 #endif
 constexpr uint32_t kChunk = RRT_CHUNK;   // samples of each pixel handled by one wave item
-constexpr uint32_t kMaxStackDepth = 64;  // LDS short stack: entries per lane
+constexpr uint32_t kMaxStackDepth = 64;  // traversal stack: entries per lane
+constexpr uint32_t kLdsStackEntries = 34;  // k_trace_stream keeps this many of them in LDS (16 waves per compute unit), the rest in private memory
 constexpr uint32_t kDeepTreeNodes = 16;  // trees with more nodes than this take the cooperative-leaf walk
 constexpr size_t kSlabCapBytes = 16ull << 30;  // default budget of the per-sample radiance staging buffer (per scene handle, per GPU):
                                                // sized for 288 GB of HBM, so that a 1024x1024 frame at 1024 spp is a single pass
@@ -202,7 +203,8 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
     const uint32_t s0 = chunk * kChunk;
     const uint32_t ns = ta.n_samples - s0 < kChunk ? ta.n_samples - s0 : kChunk;
     const uint32_t pool = ns * 64u;
-    uint32_t* stack = lds_stack + lane;
+    uint32_t beyond[kMaxStackDepth];  // private memory; sized for any split of the stack the host may choose
+    const WalkStack stack = {lds_stack + lane, kTraceBlock, ta.stack_depth, beyond};
     unsigned char* coop = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
     enum : uint32_t { DEAD = 0, FRESH = 1, WALK = 2, LEAF = 3, READY = 4 };
 
@@ -271,7 +273,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
         }
         if (st == WALK) {
             RRT_COUNT(prof_nodes, 1);
-            walk_step<AABB_MODE>(sc, w, r, RRT_T_MIN, stack, kTraceBlock);
+            walk_step<AABB_MODE>(sc, w, r, RRT_T_MIN, stack);
             if (w.pending) {
                 st = LEAF;
                 RRT_COUNT(prof_pairs, w.n_pairs);
@@ -287,7 +289,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
 #endif
             coop_leaves<FEAT, AABB_MODE == kAabbClean>(sc, r, RRT_T_MIN, g, depth, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
             if (st == LEAF) {
-                walk_resume(w, stack, kTraceBlock);
+                walk_resume(w, stack);
                 st = w.running ? WALK : READY;
             }
         }
@@ -457,6 +459,7 @@ struct rrt_scene {
     size_t slab_bytes = 0;
     size_t slab_cap = kSlabCapBytes;
     uint32_t res_x = 0, res_y = 0, samples = 0, stack_depth = 1;
+    uint32_t lds_stack = kLdsStackEntries;  // deep trees: stack entries per lane that k_trace_stream keeps in LDS
     uint32_t features = 0;  // F_* bits the scene needs
     bool deep = false;      // many-node tree: kernels use the cooperative-leaf walk (closest_hit_deep)
     bool clean = false;     // tree built with RRT_AGGREGATE_BVH_CLEAN: traversal mode kAabbClean, whatever the caller asks for
@@ -931,6 +934,13 @@ int rrt_scene_set_staging_limit(rrt_scene* s, uint64_t bytes) {
     return RRT_OK;
 }
 
+int rrt_scene_set_lds_stack(rrt_scene* s, uint32_t entries) {
+    if (!s) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_set_lds_stack: NULL scene");
+    if (entries > kMaxStackDepth) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_set_lds_stack: at most 64 entries");
+    s->lds_stack = entries ? entries : kLdsStackEntries;
+    return RRT_OK;
+}
+
 int rrt_scene_set_timing(rrt_scene* s, int enable) {
     if (!s) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_set_timing: NULL scene");
     s->timing = enable != 0;
@@ -1084,8 +1094,8 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         HIP_TRY(hipMalloc((void**)&s->slab, need_bytes));
         s->slab_bytes = need_bytes;
     }
-    const size_t lds = (size_t)kTraceBlock * s->stack_depth * sizeof(uint32_t) + (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave + kHarvestBytesPerWave);
-    ta.stack_depth = s->stack_depth;
+    ta.stack_depth = s->deep && s->stack_depth > s->lds_stack ? s->lds_stack : s->stack_depth;
+    const size_t lds = (size_t)kTraceBlock * ta.stack_depth * sizeof(uint32_t) + (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave + kHarvestBytesPerWave);
     ta.coop_lanes = 16;   // measured on a 500 000-triangle mesh, 1024x1024 @ 64 spp: 8/16 -> 398 ms, 16/16 -> 344 ms, 24/12 -> 340 ms,
     ta.shade_lanes = 16;  // 32/32 -> 440 ms, 48/48 -> 728 ms (paused / finished lanes that trigger a leaf / shading phase)
     hipStream_t st = (hipStream_t)stream;

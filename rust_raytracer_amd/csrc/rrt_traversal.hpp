@@ -288,6 +288,23 @@ struct Walk {
     f3 inv;
     Hit h;
 };
+// A lane's stack of pending links.  The first lds_entries places sit in LDS ([entry][lane]); places beyond them - reached only
+// on unusually long descents - sit in the lane's private memory, so that the LDS request (and with it the number of waves a
+// compute unit holds) follows the common case and not the tree's worst case.
+struct WalkStack {
+    uint32_t* lds;
+    uint32_t stride, lds_entries;
+    uint32_t* beyond;
+};
+RRT_DEV void stack_push(const WalkStack& s, uint32_t& sp, uint32_t link) {
+    if (sp < s.lds_entries) s.lds[sp * s.stride] = link;
+    else s.beyond[sp - s.lds_entries] = link;
+    ++sp;
+}
+RRT_DEV uint32_t stack_pop(const WalkStack& s, uint32_t& sp) {
+    --sp;
+    return sp < s.lds_entries ? s.lds[sp * s.stride] : s.beyond[sp - s.lds_entries];
+}
 RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, float t_max) {
     w.h.slot = -1;
     w.h.t = t_max;
@@ -302,7 +319,7 @@ RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, fl
 // Visits one node (BVH::hit, aggregate.rs:343-395): an inner node that passes its test pushes one child and descends into the
 // other, a leaf that passes pauses the walk, anything else pops.
 template <int AABB_MODE>
-RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, uint32_t* stack, uint32_t stride) {
+RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, const WalkStack& stack) {
     const cv4p cnodes = sc.c_nodes();
     if (AABB_MODE == kAabbClean) {
         // One 128-byte fetch brings the boxes of up to four children: only children the ray meets are ever fetched themselves,
@@ -335,21 +352,14 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, uin
         RRT_ORDER(key[0], key[1]) RRT_ORDER(key[2], key[3]) RRT_ORDER(key[0], key[2]) RRT_ORDER(key[1], key[3]) RRT_ORDER(key[1], key[2])
 #undef RRT_ORDER
         if (key[0] == ~0ull) {
-            if (w.sp == 0) {
-                w.running = false;
-            } else {
-                --w.sp;
-                w.cur = stack[w.sp * stride];
-            }
+            if (w.sp == 0) w.running = false;
+            else w.cur = stack_pop(stack, w.sp);
             return;
         }
         w.cur = (uint32_t)key[0];
 #pragma unroll
         for (int k = 3; k >= 1; --k)
-            if (key[k] != ~0ull) {
-                stack[w.sp * stride] = (uint32_t)key[k];
-                ++w.sp;
-            }
+            if (key[k] != ~0ull) stack_push(stack, w.sp, (uint32_t)key[k]);
         return;
     }
     const v4f n0 = cnodes[4 * w.cur];
@@ -366,8 +376,7 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, uin
         const float dax = b == 0u ? r.d.x : (b == 1u ? r.d.y : r.d.z);
         const uint32_t left = w.cur + 1u, right = a;
         const bool left_first = dax < 0.0f;
-        stack[w.sp * stride] = left_first ? right : left;
-        ++w.sp;
+        stack_push(stack, w.sp, left_first ? right : left);
         w.cur = left_first ? left : right;
     } else if (inside) {
         w.pending = true;  // the leaf is tested in the next cooperative phase; the walk resumes after it
@@ -377,23 +386,22 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, uin
     } else if (w.sp == 0) {
         w.running = false;
     } else {
-        --w.sp;
-        w.cur = stack[w.sp * stride];
+        w.cur = stack_pop(stack, w.sp);
     }
 }
 // After the cooperative phase that tested this lane's leaf.
-RRT_DEV void walk_resume(Walk& w, uint32_t* stack, uint32_t stride) {
+RRT_DEV void walk_resume(Walk& w, const WalkStack& stack) {
     w.pending = false;
     if (w.sp != 0) {
-        --w.sp;
-        w.cur = stack[w.sp * stride];
+        w.cur = stack_pop(stack, w.sp);
         w.running = true;
     }
 }
 
 template <int AABB_MODE, uint32_t FEAT>
-RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack,
+RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* lds_stack,
                              uint32_t stride, unsigned char* coop) {
+    const WalkStack stack = {lds_stack, stride, 0xffffffffu, nullptr};  // the caller's LDS holds the whole stack
     // Must be called by all 64 lanes of the wave (the cooperative phase addresses lanes by number); lanes without a ray
     // pass active = false and only lend a hand.
     Walk w;
@@ -404,7 +412,7 @@ RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float 
     for (;;) {
         if (w.running) {
             RRT_COUNT(prof_nodes, 1);
-            walk_step<AABB_MODE>(sc, w, r, t_min, stack, stride);
+            walk_step<AABB_MODE>(sc, w, r, t_min, stack);
             if (w.pending) RRT_COUNT(prof_pairs, w.n_pairs);
         }
         const unsigned long long waiting = RRT_BALLOT(w.pending), walking = RRT_BALLOT(w.running);
@@ -416,7 +424,7 @@ RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float 
             if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_leaf_steps;
 #endif
             coop_leaves<FEAT, AABB_MODE == kAabbClean>(sc, r, t_min, key, depth, w.pending, w.first_pair, w.n_pairs, w.h, coop);
-            if (w.pending) walk_resume(w, stack, stride);
+            if (w.pending) walk_resume(w, stack);
         } else if (waiting == 0ull && walking == 0ull) {
             break;
         }

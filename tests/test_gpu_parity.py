@@ -270,6 +270,23 @@ def test_clean_bvh_returns_what_the_list_aggregate_returns(gpu, case):
     assert st["rays"] == int(st_ref[0])
 
 
+@pytest.mark.parametrize("tree", ["BVH", "BVH_CLEAN"])
+def test_stack_split_between_lds_and_private_memory_changes_nothing(gpu, tree):
+    """rrt_scene_set_lds_stack: with only one or three stack entries in LDS nearly every push and pop goes to the lane's private
+    memory; the frame must stay bit-identical to the default split's (and so to the oracle's, which other tests check)."""
+    d = synth.terrain_desc(70, seed=4, width=48, height=40, samples=3)
+    g = rrt.Scene(synth.host_scene(d, tree))
+    ref, st_ref = g.render(seed=3, background=rrt.BG_SKY)
+    for entries in (1, 3, 64, 0):
+        g.set_lds_stack(entries)
+        img, st = g.render(seed=3, background=rrt.BG_SKY)
+        same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), "%d of %d values differ with %d entries in LDS" % ((~same).sum(), same.size, entries)
+        assert st["rays"] == st_ref["rays"]
+    with pytest.raises(rrt.RrtError):
+        g.set_lds_stack(65)
+
+
 def test_light_densities_come_from_the_shape_not_from_the_tree(gpu):
     """Single-leaf scene whose light (a scaled sphere) sticks out of the leaf's box: the reference's tree misses it there, but
     Sphere::pdf (shape.rs:141-147) asks the sphere itself; the harvesting kernel must reproduce both."""

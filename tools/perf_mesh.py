@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""GPU-box timing of the synthetic displaced-grid mesh: python tools/perf_mesh.py N W H SPP [tight] [host|clean]  (2*N*N triangles;
+"""GPU-box timing of the synthetic displaced-grid mesh: python tools/perf_mesh.py N W H SPP [tight] [host|clean] [lds=K]  (2*N*N triangles;
 "host" builds the tree on the host instead of the GPU)."""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -16,6 +16,9 @@ t0 = time.time()
 hs = synth.host_scene(d, "BVH" if "host" in sys.argv else ("BVH_CLEAN" if "clean" in sys.argv else "BVH_GPU"))
 t1 = time.time()
 sc = rrt.Scene(hs)
+for a in sys.argv:
+    if a.startswith("lds="):
+        sc.set_lds_stack(int(a[4:]))  # stack entries per ray kept in LDS
 t2 = time.time()
 print("triangles %d nodes %d depth %d: scene + tree build %.2f s, upload %.2f s" % (2 * n * n, hs.desc.n_nodes, hs.desc.bvh_depth, t1 - t0, t2 - t1), flush=True)
 img = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
