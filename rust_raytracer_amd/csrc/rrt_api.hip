@@ -1097,8 +1097,8 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
     }
     ta.stack_depth = s->deep && s->stack_depth > s->lds_stack ? s->lds_stack : s->stack_depth;
     const size_t lds = (size_t)kTraceBlock * ta.stack_depth * sizeof(uint32_t) + (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave + kHarvestBytesPerWave);
-    ta.coop_lanes = 16;   // measured on a 500 000-triangle mesh, 1024x1024 @ 64 spp: 8/16 -> 398 ms, 16/16 -> 344 ms, 24/12 -> 340 ms,
-    ta.shade_lanes = 16;  // 32/32 -> 440 ms, 48/48 -> 728 ms (paused / finished lanes that trigger a leaf / shading phase)
+    ta.coop_lanes = 24;   // paused / finished lanes that trigger a leaf / shading phase; measured on a 500 000-triangle mesh with a
+    ta.shade_lanes = 16;  // clean tree, 1024x1024 @ 64 spp: 8/16 -> 172 ms, 16/16 -> 147 ms, 24/16 -> 140 ms, 32/16 -> 143 ms, 16/8 -> 154 ms, 16/32 -> 152 ms
     hipStream_t st = (hipStream_t)stream;
     // compiled variants: plain (triangles + spheres, constant textures), textured (+ textures, bump maps), full (+ media)
     constexpr uint32_t kPlain = F_SPHERE, kTextured = F_SPHERE | F_TEX | F_BUMP;

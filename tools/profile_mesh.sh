@@ -1,12 +1,12 @@
 #!/bin/bash
 # Kernel trace and HBM-traffic counters for the streaming kernel on the synthetic 10 M-triangle mesh with a clean tree (GPU box):
-#   bash tools/profile_mesh.sh <out-dir-under-gpurun_out>
+#   [MESH_ARGS="N W H SPP tight clean"] bash tools/profile_mesh.sh <out-dir-under-gpurun_out>
 # Each rocprofv3 pass is its own run; counters are never combined with API traces.
 set -e
 out=gpurun_out/${1:-prof_mesh}
 mkdir -p "$out"
 export TMPDIR=/tmp
-B="python3 tools/perf_mesh.py 2236 1024 576 64 tight clean"
+B="python3 tools/perf_mesh.py ${MESH_ARGS:-2236 3840 2160 16 tight clean}"
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- $B > "$out/run_trace.txt"
 timeout -s KILL 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- $B > "$out/run_fetch.txt"
 timeout -s KILL 600 rocprofv3 --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/pmc_write" -- $B > "$out/run_write.txt"
