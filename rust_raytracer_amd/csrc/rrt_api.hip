@@ -36,7 +36,7 @@ struct TraceArgs {
     uint32_t tile_count, tile_index, tiles_x, n_tiles;  // 32x32-pixel tiles (multi-GPU sharding unit)
     uint32_t n_t8;                                       // 8x8-pixel wave tiles owned by this call
     uint32_t stack_depth;                                // LDS stack entries per lane (the cooperative-leaf area follows the stack)
-    uint32_t chunk;                                      // k_trace_stream: samples of each pixel handled by one wave item (divides kChunk)
+    uint32_t chunk;                                      // samples of each pixel handled by one wave item (divides kChunk)
     uint32_t coop_lanes, shade_lanes;                    // k_trace_stream: paused / finished lanes that trigger a leaf / shading phase
 };
 
@@ -61,8 +61,8 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
     const uint32_t tile32 = ta.tile_index + (j >> 4) * ta.tile_count;
     const uint32_t x0 = (tile32 % ta.tiles_x) * 32u + ((j & 3u) << 3);
     const uint32_t y0 = (tile32 / ta.tiles_x) * 32u + (((j >> 2) & 3u) << 3);
-    const uint32_t s0 = chunk * kChunk;
-    const uint32_t ns = ta.n_samples - s0 < kChunk ? ta.n_samples - s0 : kChunk;
+    const uint32_t s0 = chunk * ta.chunk;
+    const uint32_t ns = ta.n_samples - s0 < ta.chunk ? ta.n_samples - s0 : ta.chunk;
     const uint32_t pool = ns * 64u;
     uint32_t* stack = lds_stack + lane;
 
@@ -1118,15 +1118,16 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         }
         ta.n_samples = plan.spp - done < per_pass ? plan.spp - done : (uint32_t)per_pass;
         ta.first_sample = plan.ta.first_sample + done;
-        // Deep trees: a wave item is long (thousands of dependent node fetches per sample pool), so a frame of few items ends in
-        // a long tail of half-empty compute units; smaller pools until there are enough items to keep the tail short.
+        // A frame of few wave items ends in a tail of half-empty compute units (and cannot balance long and short items):
+        // smaller sample pools until the pass has ten items per wave place of the chip (256 compute units x 16).  Pools below
+        // 16 samples per pixel cost more in ramp-up and drain than they balance, except on deep trees, where an item is long
+        // (thousands of dependent node fetches).  Measured: Cornell_Box 512x512@64 4.77 -> 3.53 ms, Materials 640x360@64 6.20 ->
+        // 2.41 ms, headline scene 1024x1024@128 39.9 -> 38.1 ms; 500 000 triangles 1024x1024@64: pools of 64 / 32 / 16 / 8 -> 197
+        // / 161 / 147 / 150 ms; 10 M triangles 1024x576@64: 64 -> 640 ms, 8 -> 252 ms, 4 -> 265 ms.
+        constexpr uint64_t want = 40960;
+        const uint32_t least = s->deep ? 4u : 16u;
         ta.chunk = kChunk;
-        if (s->deep) {
-            // ten items per wave place of the chip (256 compute units x 16); measured, 1024x1024 @ 64 spp on 500 000 triangles:
-            // pools of 64 / 32 / 16 / 8 samples per pixel -> 197 / 161 / 147 / 150 ms; 10 M triangles, 1024x576: 64 -> 640 ms, 8 -> 252 ms
-            constexpr uint64_t want = 40960;
-            while (ta.chunk > 4u && (uint64_t)((ta.n_samples + ta.chunk - 1) / ta.chunk) * ta.n_t8 < want) ta.chunk /= 2u;
-        }
+        while (ta.chunk > least && (uint64_t)((ta.n_samples + ta.chunk - 1) / ta.chunk) * ta.n_t8 < want) ta.chunk /= 2u;
         const uint64_t items = (uint64_t)((ta.n_samples + ta.chunk - 1) / ta.chunk) * ta.n_t8;
         if (items > 0x7fffffffull) return rrt_set_error(RRT_ERR_LIMIT, "rrt_render: too many work items in one pass");
         const dim3 grid((unsigned)items);
