@@ -346,7 +346,9 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, const float* __
     Hit h;
     if (DEEP) {
         unsigned char* coop = (unsigned char*)(lds_stack + kBlock * stack_depth) + (threadIdx.x >> 6) * kCoopBytesPerWave;
-        h = closest_hit_deep<AABB_MODE, F_ALL>(sc, active, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock, coop);
+        uint32_t beyond[kMaxStackDepth];  // private memory: stack entries past the stack_depth ones kept in LDS
+        const WalkStack stack = {lds_stack + threadIdx.x, kBlock, stack_depth, beyond};
+        h = closest_hit_deep<AABB_MODE, F_ALL>(sc, active, r, t_min, t_max, g, 0, stack, coop);
     } else {
         unsigned char* area = (unsigned char*)(lds_stack + kBlock * stack_depth) + (threadIdx.x >> 6) * kSiftBytesPerWave;
         h = closest_hit_sift<AABB_MODE, F_ALL>(sc, active, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock, area);
@@ -992,16 +994,17 @@ int rrt_intersect_batch_device(rrt_scene* s, const float* d_o, const float* d_d,
     if (n == 0) return RRT_OK;
     if (n > (size_t)0x7fffffff * kBlock) return rrt_set_error(RRT_ERR_LIMIT, "rrt_intersect_batch: too many rays for one launch");
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-    size_t lds = (size_t)kBlock * s->stack_depth * sizeof(uint32_t) + (size_t)(kBlock / 64) * (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave);
+    const uint32_t lds_entries = s->deep && s->stack_depth > s->lds_stack ? s->lds_stack : s->stack_depth;  // deep trees: the rest in private memory
+    size_t lds = (size_t)kBlock * lds_entries * sizeof(uint32_t) + (size_t)(kBlock / 64) * (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave);
     hipStream_t st = (hipStream_t)stream;
     if (s->clean)
-        hipLaunchKernelGGL((k_intersect<kAabbClean, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
+        hipLaunchKernelGGL((k_intersect<kAabbClean, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, d_prim, d_t);
     else if (aabb_mode == RRT_AABB_REFERENCE)
-        if (s->deep) hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
-        else hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE, false>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
+        if (s->deep) hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, d_prim, d_t);
+        else hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE, false>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, d_prim, d_t);
     else
-        if (s->deep) hipLaunchKernelGGL((k_intersect<RRT_AABB_TIGHT, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
-        else hipLaunchKernelGGL((k_intersect<RRT_AABB_TIGHT, false>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
+        if (s->deep) hipLaunchKernelGGL((k_intersect<RRT_AABB_TIGHT, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, d_prim, d_t);
+        else hipLaunchKernelGGL((k_intersect<RRT_AABB_TIGHT, false>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, d_prim, d_t);
     HIP_TRY(hipGetLastError());
     return RRT_OK;
 }

@@ -399,9 +399,8 @@ RRT_DEV void walk_resume(Walk& w, const WalkStack& stack) {
 }
 
 template <int AABB_MODE, uint32_t FEAT>
-RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* lds_stack,
-                             uint32_t stride, unsigned char* coop) {
-    const WalkStack stack = {lds_stack, stride, 0xffffffffu, nullptr};  // the caller's LDS holds the whole stack
+RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, const WalkStack& stack,
+                             unsigned char* coop) {
     // Must be called by all 64 lanes of the wave (the cooperative phase addresses lanes by number); lanes without a ray
     // pass active = false and only lend a hand.
     Walk w;

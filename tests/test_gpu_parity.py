@@ -277,8 +277,13 @@ def test_stack_split_between_lds_and_private_memory_changes_nothing(gpu, tree):
     d = synth.terrain_desc(70, seed=4, width=48, height=40, samples=3)
     g = rrt.Scene(synth.host_scene(d, tree))
     ref, st_ref = g.render(seed=3, background=rrt.BG_SKY)
+    ro, rd = raygen.ray_batch(orc.OracleScene(d), 48, 40, n_random=3000, seed=5)
+    p_ref, t_ref = g.hit(ro, rd)
+    assert (p_ref >= 0).sum() > 1000
     for entries in (1, 3, 64, 0):
         g.set_lds_stack(entries)
+        p, t = g.hit(ro, rd)  # the ray-batch kernel splits its stack the same way
+        assert np.array_equal(p, p_ref) and np.array_equal(bits(t), bits(t_ref))
         img, st = g.render(seed=3, background=rrt.BG_SKY)
         same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
         assert same.all(), "%d of %d values differ with %d entries in LDS" % ((~same).sum(), same.size, entries)
