@@ -222,7 +222,11 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
     Walk w;
     walk_begin(sc, w, false, r, RRT_T_MAX);
 #ifdef RRT_PHASE_PROFILE
-    unsigned long long prof_nodes = 0, prof_pairs = 0, prof_steps = 0, prof_leaf_steps = 0;
+    unsigned long long prof_nodes = 0, prof_pairs = 0, prof_steps = 0, prof_leaf_steps = 0, cyc_shade = 0, cyc_walk = 0, cyc_leaf = 0, n_shade = 0;
+    unsigned long long tick = __builtin_readcyclecounter();
+#define RRT_STREAM_TICK(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tick; tick = now_; }
+#else
+#define RRT_STREAM_TICK(acc)
 #endif
     for (;;) {
         const unsigned long long walking = RRT_BALLOT(st == WALK), paused = RRT_BALLOT(st == LEAF), waiting = RRT_BALLOT(st == READY || st == FRESH);
@@ -270,6 +274,8 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
                 st = idx < pool ? FRESH : DEAD;
             }
             next += (uint32_t)__popcll(finished);
+            RRT_STREAM_TICK(cyc_shade);
+            RRT_COUNT(n_shade, 1);
             continue;
         }
         if (st == WALK) {
@@ -283,6 +289,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
 #ifdef RRT_PHASE_PROFILE
         if (lane == 0) ++prof_steps;
 #endif
+        RRT_STREAM_TICK(cyc_walk);
         const unsigned long long at_leaf = RRT_BALLOT(st == LEAF);
         if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= ta.coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
 #ifdef RRT_PHASE_PROFILE
@@ -293,9 +300,17 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
                 walk_resume(w, stack);
                 st = w.running ? WALK : READY;
             }
+            RRT_STREAM_TICK(cyc_leaf);
         }
     }
+#undef RRT_STREAM_TICK
 #ifdef RRT_PHASE_PROFILE
+    if (lane == 0) {
+        atomicAdd(&g_prof[4], cyc_shade);
+        atomicAdd(&g_prof[5], cyc_walk);
+        atomicAdd(&g_prof[6], cyc_leaf);
+        atomicAdd(&g_prof[7], n_shade);
+    }
     atomicAdd(&g_prof[0], prof_nodes);
     atomicAdd(&g_prof[1], prof_pairs);
     atomicAdd(&g_prof[2], prof_steps);

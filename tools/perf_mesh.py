@@ -42,4 +42,8 @@ for mode, name in ((rrt.AABB_TIGHT, "tight"), (rrt.AABB_REFERENCE, "reference"))
         rays = max(int(cnt[0]), 1)
         print("  per ray: %.1f node visits, %.1f pair tests; per wave-query: node steps %.1f, pair steps %.1f (wave-queries ~ rays/64 = %d)" % (
             out[0] / rays, out[1] / rays, out[2] / (rays / 64), out[3] / (rays / 64), rays // 64))
+        cyc = float(out[4] + out[5] + out[6])
+        if cyc:
+            print("  wave cycles: shading %.1f %% (%.0f per phase), node steps %.1f %% (%.0f per step), leaf phases %.1f %% (%.0f per phase)" % (
+                100 * out[4] / cyc, out[4] / max(int(out[7]), 1), 100 * out[5] / cyc, out[5] / max(int(out[2]), 1), 100 * out[6] / cyc, out[6] / max(int(out[3]), 1)))
     print("%-9s %dx%d@%d: %.2f ms  rays=%d  %.3f Grays/s  mean=%.5f" % (name, W, H, spp, ms, int(cnt[0]), int(cnt[0]) / ms / 1e6, float(img.mean()) / spp), flush=True)
