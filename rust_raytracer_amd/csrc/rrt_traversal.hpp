@@ -286,6 +286,7 @@ struct Walk {
     bool pending;  // stands at a leaf (first_pair, n_pairs) that the next cooperative phase tests
     uint32_t first_pair, n_pairs;
     f3 inv;
+    uint32_t down;  // bit c: the ray runs towards smaller coordinates on axis c
     Hit h;
 };
 // A lane's stack of pending links.  The first lds_entries places sit in LDS ([entry][lane]); places beyond them - reached only
@@ -315,6 +316,7 @@ RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, fl
     w.first_pair = w.n_pairs = 0;
     w.running = active && sc.n_nodes != 0;
     w.inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    w.down = (w.inv.x < 0.0f ? 1u : 0u) | (w.inv.y < 0.0f ? 2u : 0u) | (w.inv.z < 0.0f ? 4u : 0u);
 }
 // Visits one node (BVH::hit, aggregate.rs:343-395): an inner node that passes its test pushes one child and descends into the
 // other, a leaf that passes pauses the walk, anything else pops.
@@ -333,14 +335,19 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, con
             return;
         }
         const uint32_t base = 8u * w.cur;
-        const v4f lox = cnodes[base], hix = cnodes[base + 1], loy = cnodes[base + 2], hiy = cnodes[base + 3], loz = cnodes[base + 4],
-                  hiz = cnodes[base + 5], links = cnodes[base + 6];
+        // The ray's direction signs pick, per axis, which of the two plane quads is the near one: the loads fetch (near, far)
+        // instead of (lo, hi) and the interval test needs no per-axis minimum and maximum.
+        const uint32_t sx = w.down & 1u, sy = (w.down >> 1) & 1u, sz = w.down >> 2;
+        const v4f nx = cnodes[base + sx], fx = cnodes[base + (sx ^ 1u)], ny = cnodes[base + 2u + sy], fy = cnodes[base + 2u + (sy ^ 1u)],
+                  nz = cnodes[base + 4u + sz], fz = cnodes[base + 4u + (sz ^ 1u)], links = cnodes[base + 6];
         unsigned long long key[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            float entry;
             const uint32_t link = __float_as_uint(links[k]);
-            const bool met = box_span(lox[k], hix[k], loy[k], hiy[k], loz[k], hiz[k], r.o, w.inv, t_min, w.h.t, &entry) && link != kLinkNone;
+            // NaN (0 * inf: the ray lies in a plane of the box) is dropped by the maxima and minima: that plane constrains nothing
+            const float entry = __builtin_fmaxf(__builtin_fmaxf((nx[k] - r.o.x) * w.inv.x, (ny[k] - r.o.y) * w.inv.y), __builtin_fmaxf((nz[k] - r.o.z) * w.inv.z, t_min));
+            const float leave = __builtin_fminf(__builtin_fminf((fx[k] - r.o.x) * w.inv.x, (fy[k] - r.o.y) * w.inv.y), __builtin_fminf((fz[k] - r.o.z) * w.inv.z, w.h.t));
+            const bool met = entry <= leave && link != kLinkNone;
             key[k] = met ? (((unsigned long long)ord_bits(entry) << 32) | link) : ~0ull;
         }
 #define RRT_ORDER(a, b)                                   \
