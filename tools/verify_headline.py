@@ -22,8 +22,21 @@ t0 = time.perf_counter()
 img, st = rrt.Scene.load(path, width=W, height=H, samples=spp).render(seed=0)
 t1 = time.perf_counter()
 threads = min(16, len(os.sched_getaffinity(0)))
+print("GPU frame done in %.2f s; CPU oracle on %d threads ..." % (t1 - t0, threads), flush=True)
+import threading  # noqa: E402
+
+done = threading.Event()
+
+
+def heartbeat():  # a long silent run looks hung to whoever watches the job
+    while not done.wait(30.0):
+        print("  oracle still rendering, %.0f s" % (time.perf_counter() - t1), flush=True)
+
+
+threading.Thread(target=heartbeat, daemon=True).start()
 ref, st_ref = orc.OracleScene.from_file(path, {"resolution_x": W, "resolution_y": H, "samples": spp}).render(W, H, spp, seed=0, threads=threads)
 t2 = time.perf_counter()
+done.set()
 same = (img.view(np.uint32) == ref.view(np.uint32)) | (np.isnan(img) & np.isnan(ref))
 print("1024x1024 @ %d spp: GPU %d rays, oracle %d rays; %d of %d radiance sums differ; %d NaN sums; GPU call %.2f s, oracle %.1f s on %d threads" % (
     spp, st["rays"], int(st_ref[0]), int((~same).sum()), same.size, int(np.isnan(ref).sum()), t1 - t0, t2 - t1, threads))
