@@ -348,7 +348,9 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, con
             const float entry = __builtin_fmaxf(__builtin_fmaxf((nx[k] - r.o.x) * w.inv.x, (ny[k] - r.o.y) * w.inv.y), __builtin_fmaxf((nz[k] - r.o.z) * w.inv.z, t_min));
             const float leave = __builtin_fminf(__builtin_fminf((fx[k] - r.o.x) * w.inv.x, (fy[k] - r.o.y) * w.inv.y), __builtin_fminf((fz[k] - r.o.z) * w.inv.z, w.h.t));
             const bool met = entry <= leave && link != kLinkNone;
-            key[k] = met ? (((unsigned long long)ord_bits(entry) << 32) | link) : ~0ull;
+            // entry >= t_min: with a positive lower bound (a constant in the render kernels) the float's own bits order correctly
+            const uint32_t order = t_min > 0.0f ? __float_as_uint(entry) : ord_bits(entry);
+            key[k] = met ? (((unsigned long long)order << 32) | link) : ~0ull;
         }
 #define RRT_ORDER(a, b)                                   \
     {                                                     \
