@@ -41,6 +41,19 @@ def terrain_desc(n, seed=1, width=64, height=64, samples=2, amplitude=0.15, cull
     }
 
 
+def soup_desc(n=3000, seed=7, width=40, height=32, samples=2):
+    """n random triangles in [-1,1]^3 with sizes over three orders of magnitude (a few span the whole scene), one object, lit
+    by a quad above: boxes that overlap heavily, unlike the terrain's tidy grid."""
+    rng = np.random.default_rng(seed)
+    centre = rng.uniform(-1.0, 1.0, (n, 1, 3))
+    size = 10.0 ** rng.uniform(-3.0, 0.0, (n, 1, 1))
+    verts = (centre + size * rng.uniform(-1.0, 1.0, (n, 3, 3))).reshape(-1, 3).astype(np.float64)
+    tris = np.arange(3 * n, dtype=np.int32).reshape(n, 3)
+    d = terrain_desc(2, seed=seed, width=width, height=height, samples=samples)
+    d["shapes"][0]["object"] = {"vertices": verts, "tex": np.zeros((0, 2)), "vidx": tris, "tidx": np.full_like(tris, -1)}
+    return d
+
+
 def spheres_desc(n=40, seed=3, width=48, height=40, samples=4, media=0):
     """Rotated, anisotropically scaled spheres (whose reference bounding box, centre +- radius, ignores the scale and so does
     not contain them), a few with negative radius, over a two-triangle floor; Lambert, Metal, Dielectric and one light."""

@@ -240,7 +240,7 @@ def test_one_big_leaf_with_ties_bit_exact(gpu, aggregate, n):
         assert st["rays"] == int(st_ref[0])
 
 
-@pytest.mark.parametrize("case", ["terrain", "terrain39k", "slats", "spheres", "coincident"])
+@pytest.mark.parametrize("case", ["terrain", "terrain39k", "soup", "slats", "spheres", "coincident"])
 def test_clean_bvh_returns_what_the_list_aggregate_returns(gpu, case):
     """RRT_AGGREGATE_BVH_CLEAN (a tree of its own, built on the device) against the oracle's LIST aggregate: nearest hit, equal
     distances to the shape that is first in scene order, bit-exact distances; rendered frames bit-exact too."""
@@ -248,6 +248,8 @@ def test_clean_bvh_returns_what_the_list_aggregate_returns(gpu, case):
         d = synth.terrain_desc(60, seed=3, width=40, height=40, samples=2)
     elif case == "terrain39k":  # a deeper tree; ray batches only (the List oracle tests every triangle for every ray)
         d = synth.terrain_desc(140, seed=2, width=16, height=16, samples=1)
+    elif case == "soup":
+        d = synth.soup_desc()  # boxes that overlap heavily, triangles from a thousandth of the scene to all of it
     elif case == "slats":
         d = synth.slats_desc(n=40, aggregate=0)  # shapes duplicated in place: exact ties
     elif case == "coincident":
@@ -338,7 +340,7 @@ def _same_records(a, b):
     return a.dtype == b.dtype and a.shape == b.shape and a.tobytes() == b.tobytes()
 
 
-@pytest.mark.parametrize("case", ["terrain20k", "terrain180k", "spheres", "slats", "cornell", "tiny2", "tiny6", "tiny8"])
+@pytest.mark.parametrize("case", ["terrain20k", "terrain180k", "soup", "spheres", "slats", "cornell", "tiny2", "tiny6", "tiny8"])
 def test_gpu_built_bvh_equals_the_host_built_one(gpu, case):
     """RRT_AGGREGATE_BVH_GPU must give the reference's tree bit for bit: node boxes (signed zeros included), cut axes, child
     links, leaf ranges and the order of the shapes in the leaves, also where box centres tie (the sort must be stable)."""
@@ -347,6 +349,8 @@ def test_gpu_built_bvh_equals_the_host_built_one(gpu, case):
         d = synth.terrain_desc(100, seed=2)
     elif case == "terrain180k":
         d = synth.terrain_desc(300, seed=5)
+    elif case == "soup":
+        d = synth.soup_desc(n=20000)
     elif case == "spheres":
         d = synth.spheres_desc(media=6)
     elif case == "slats":
