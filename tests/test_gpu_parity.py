@@ -165,11 +165,12 @@ def test_render_sample_ranges_and_tiles(gpu):
     assert np.array_equal(bits(tiled), bits(full))
 
 
-@pytest.mark.parametrize("cull", [False, True])
+@pytest.mark.parametrize("cull", [False, True, "soup"])
 def test_mesh_with_a_deep_tree_bit_exact(gpu, cull):
-    """A 20 000-triangle displaced grid (7 000-node tree, leaves of up to 54 triangles, lanes in different leaves):
-    closest hits in both traversal modes and a small render against the oracle's reference-mode traversal."""
-    d = synth.terrain_desc(100, seed=2, width=40, height=40, samples=2, cull=cull)
+    """A 20 000-triangle displaced grid (7 000-node tree, leaves of up to 54 triangles, lanes in different leaves), and a soup
+    of 3 000 triangles of very different sizes: closest hits in both traversal modes and a small render against the oracle's
+    reference-mode traversal."""
+    d = synth.soup_desc(width=40, height=40) if cull == "soup" else synth.terrain_desc(100, seed=2, width=40, height=40, samples=2, cull=cull)
     o = orc.OracleScene(d)
     g = rrt.Scene(synth.host_scene(d))
     ro, rd = raygen.ray_batch(o, 40, 40, n_random=6000, seed=9)
