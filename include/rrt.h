@@ -284,7 +284,7 @@ int rrt_render_device(rrt_scene*, const rrt_render_params* params, float* d_rgb_
 int rrt_scene_set_staging_limit(rrt_scene*, uint64_t bytes);
 
 /* Deep trees (more than 16 nodes, clean trees): how many of a ray's pending-node stack entries the render kernel keeps in
- * LDS (1..64; 0 restores the default of 34, the most that still lets a compute unit hold 16 waves); deeper entries live
+ * LDS (1..64; 0 restores the default of 32, which with the leaf phase's work area lets a compute unit hold 16 waves); deeper entries live
  * in the lane's private memory.  Changes speed only, never results.  No counterpart in the reference (its stack is a
  * Vec on the host heap, aggregate.rs:352). */
 int rrt_scene_set_lds_stack(rrt_scene*, uint32_t entries);

@@ -25,7 +25,8 @@ constexpr uint32_t kChunk = RRT_CHUNK;   // samples of each pixel handled by one
 constexpr int kWalkSteps = 4;            // k_trace_stream: node steps per turn of the wave's loop (1 / 2 / 3 / 4 / 6 measured on a 500 000-triangle
                                          // mesh: 141.6 / 134.6 / 131.7 / 132.9 / 129.7 ms; 10 M triangles at 4K: 603 / 579 / 566 / 560 / 565 ms)
 constexpr uint32_t kMaxStackDepth = 64;  // traversal stack: entries per lane
-constexpr uint32_t kLdsStackEntries = 34;  // k_trace_stream keeps this many of them in LDS (16 waves per compute unit), the rest in private memory
+constexpr uint32_t kLdsStackEntries = 32;  // k_trace_stream keeps this many of them in LDS (10 KB per wave with the cooperative area: 16 waves
+                                           // per compute unit), the rest in private memory
 constexpr uint32_t kDeepTreeNodes = 16;  // trees with more nodes than this take the cooperative-leaf walk
 constexpr size_t kSlabCapBytes = 16ull << 30;  // default budget of the per-sample radiance staging buffer (per scene handle, per GPU):
                                                // sized for 288 GB of HBM, so that a 1024x1024 frame at 1024 spp is a single pass

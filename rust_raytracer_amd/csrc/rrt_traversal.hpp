@@ -193,26 +193,67 @@ RRT_DEV float ord_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ?
 // lane is untouched, so results are those of closest_hit.
 //
 // `coop` is this wave's LDS area: 64 x u64 keys followed by 64 x (slot, det, u, v).
-constexpr uint32_t kCoopBytesPerWave = 64 * 8 + 64 * 16;
+constexpr uint32_t kCoopBytesPerWave = 64 * 8 + 64 * 16 + 128 * 4;  // closest keys, hit payloads, item list
 #ifndef RRT_COOP_LANES
 #define RRT_COOP_LANES 8
 #endif
 constexpr uint32_t kCoopLanes = RRT_COOP_LANES;  // paused lanes that trigger a cooperative leaf phase
 
+// Tests up to 64 listed (owner lane, pair position) items, one per lane, for coop_leaves().
+template <uint32_t FEAT, bool CLEAN>
+RRT_DEV void coop_group(const DScene& sc, const Ray& r, float t_min, const Rng& key, uint32_t depth, uint32_t first_pair, const Hit& h,
+                        const uint32_t* items, uint32_t n_items, unsigned long long* best, v4f* payload) {
+    const uint32_t lane = threadIdx.x & 63u;
+    const bool have = lane < n_items;
+    const uint32_t item = have ? items[lane] : lane;
+    const int owner = (int)(item & 63u);
+    const uint32_t k = item >> 6;  // position of the pair in its leaf
+    const uint32_t o_first = (uint32_t)__shfl((int)first_pair, owner);
+    Ray ro;
+    ro.o = mk3(__shfl(r.o.x, owner), __shfl(r.o.y, owner), __shfl(r.o.z, owner));
+    ro.d = mk3(__shfl(r.d.x, owner), __shfl(r.d.y, owner), __shfl(r.d.z, owner));
+    const float o_t = __shfl(h.t, owner);
+    Rng okey = key;
+    uint32_t odepth = depth;
+    if (FEAT & F_MEDIUM) {  // the medium's distance draw is keyed by the owner's stream and depth
+        okey.s0 = (uint32_t)__shfl((int)key.s0, owner);
+        okey.s1 = (uint32_t)__shfl((int)key.s1, owner);
+        odepth = (uint32_t)__shfl((int)depth, owner);
+    }
+    Hit hh;
+    hh.slot = -1;
+    hh.t = o_t;
+    if (CLEAN && __shfl(h.slot, owner) >= 0) hh.t = ord_float(ord_bits(o_t) + 1u);  // an equal distance may still win on shape order
+    hh.u = hh.v = hh.det = 0.0f;
+    unsigned long long mykey = ~0ull;
+    if (have) {
+        const cv4p rec = sc.c_pairs() + kPairQuads * (o_first + k);
+        test_pair<FEAT>(sc, rec, ro, t_min, okey, odepth, hh);
+        if (hh.slot >= 0) {
+            uint32_t pos = (uint32_t)hh.slot;
+            if (CLEAN) {
+                const v4f q5 = rec[5];  // (slot A, slot B, shape A, shape B)
+                pos = __float_as_uint(pos == __float_as_uint(q5.x) ? q5.z : q5.w);
+            }
+            mykey = ((unsigned long long)ord_bits(hh.t) << 32) | (unsigned long long)(pos + 1u);
+            atomicMin(&best[owner], mykey);
+        }
+    }
+    __threadfence_block();
+    if (hh.slot >= 0 && best[owner] == mykey) payload[owner] = v4f{__uint_as_float((uint32_t)hh.slot), hh.det, hh.u, hh.v};
+    __threadfence_block();
+}
+
+// The cooperative leaf phase: every pending lane stands at a leaf (first_pair, n_pairs); the wave lists all (lane, pair) items
+// - position by position, compacted with a ballot and a prefix count, no cross-lane shuffles - and tests them 64 at a time, any
+// lane testing any owner's pair.  Must be called by all 64 lanes.
 template <uint32_t FEAT, bool CLEAN>
 RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng& key, uint32_t depth, bool pending, uint32_t first_pair, uint32_t n_pairs,
                          Hit& h, unsigned char* coop) {
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long* best = (unsigned long long*)coop;
     v4f* payload = (v4f*)(coop + 64 * 8);
-    // inclusive prefix sum of the pair counts over the wave (lanes that are not in this call contribute nothing)
-    const uint32_t mine = pending ? n_pairs : 0u;
-    uint32_t incl = mine;
-    for (uint32_t off = 1; off < 64; off <<= 1) {
-        const uint32_t up = (uint32_t)__shfl_up((int)incl, off);
-        if (lane >= off) incl += up;
-    }
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    uint32_t* items = (uint32_t*)(coop + 64 * 8 + 64 * 16);  // 128 places: a group being filled plus one position's worth of items
     // Ties: in the reference's tree the leaf visited first wins, so what the owner already holds gets position 0; in a clean
     // tree the shape that is first in scene order wins wherever it sits, so positions are shape numbers throughout.
     uint32_t held = 0u;
@@ -220,55 +261,27 @@ RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng&
     const unsigned long long init = ((unsigned long long)ord_bits(h.t) << 32) | held;
     best[lane] = init;
     __threadfence_block();
-    const cv4p cpairs = sc.c_pairs();
-    for (uint32_t base = 0; base < total; base += 64u) {
-        const uint32_t item = base + lane;
-        const bool have = item < total;
-        // owner = first lane whose inclusive sum exceeds the item index
-        uint32_t lo = 0, hi = 63;
-        for (int it = 0; it < 6; ++it) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const uint32_t v = (uint32_t)__shfl((int)incl, (int)mid);
-            if (v <= item) lo = mid + 1; else hi = mid;
+    uint32_t count = 0;
+    for (uint32_t k = 0;; ++k) {
+        const bool has = pending && k < n_pairs;
+        const unsigned long long bal = RRT_BALLOT(has);
+        if (bal == 0ull) break;
+        if (has) {
+            const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            items[count + rank] = (k << 6) | lane;
         }
-        const int owner = (int)(have ? lo : lane);
-        const uint32_t o_incl = (uint32_t)__shfl((int)incl, owner), o_n = (uint32_t)__shfl((int)mine, owner);
-        const uint32_t o_first = (uint32_t)__shfl((int)first_pair, owner);
-        Ray ro;
-        ro.o = mk3(__shfl(r.o.x, owner), __shfl(r.o.y, owner), __shfl(r.o.z, owner));
-        ro.d = mk3(__shfl(r.d.x, owner), __shfl(r.d.y, owner), __shfl(r.d.z, owner));
-        const float o_t = __shfl(h.t, owner);
-        Rng okey = key;
-        uint32_t odepth = depth;
-        if (FEAT & F_MEDIUM) {  // the medium's distance draw is keyed by the owner's stream and depth
-            okey.s0 = (uint32_t)__shfl((int)key.s0, owner);
-            okey.s1 = (uint32_t)__shfl((int)key.s1, owner);
-            odepth = (uint32_t)__shfl((int)depth, owner);
-        }
-        Hit hh;
-        hh.slot = -1;
-        hh.t = o_t;
-        if (CLEAN && __shfl(h.slot, owner) >= 0) hh.t = ord_float(ord_bits(o_t) + 1u);  // an equal distance may still win on shape order
-        hh.u = hh.v = hh.det = 0.0f;
-        unsigned long long mykey = ~0ull;
-        if (have) {
-            const uint32_t k = item - (o_incl - o_n);  // position of the pair in its leaf
-            const cv4p rec = cpairs + kPairQuads * (o_first + k);
-            test_pair<FEAT>(sc, rec, ro, t_min, okey, odepth, hh);
-            if (hh.slot >= 0) {
-                uint32_t pos = (uint32_t)hh.slot;
-                if (CLEAN) {
-                    const v4f q5 = rec[5];  // (slot A, slot B, shape A, shape B)
-                    pos = __float_as_uint(pos == __float_as_uint(q5.x) ? q5.z : q5.w);
-                }
-                mykey = ((unsigned long long)ord_bits(hh.t) << 32) | (unsigned long long)(pos + 1u);
-                atomicMin(&best[owner], mykey);
-            }
-        }
+        count += (uint32_t)__popcll(bal);
         __threadfence_block();
-        if (hh.slot >= 0 && best[owner] == mykey) payload[owner] = v4f{__uint_as_float((uint32_t)hh.slot), hh.det, hh.u, hh.v};
-        __threadfence_block();
+        if (count >= 64u) {
+            coop_group<FEAT, CLEAN>(sc, r, t_min, key, depth, first_pair, h, items, 64u, best, payload);
+            count -= 64u;
+            const uint32_t moved = lane < count ? items[64u + lane] : 0u;
+            __threadfence_block();
+            if (lane < count) items[lane] = moved;
+            __threadfence_block();
+        }
     }
+    if (count != 0u) coop_group<FEAT, CLEAN>(sc, r, t_min, key, depth, first_pair, h, items, count, best, payload);
     if (pending && best[lane] != init) {
         const v4f w = payload[lane];
         h.t = ord_float((uint32_t)(best[lane] >> 32));
