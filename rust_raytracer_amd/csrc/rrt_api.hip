@@ -1017,7 +1017,11 @@ int rrt_intersect_batch_device(rrt_scene* s, const float* d_o, const float* d_d,
     if (n == 0) return RRT_OK;
     if (n > (size_t)0x7fffffff * kBlock) return rrt_set_error(RRT_ERR_LIMIT, "rrt_intersect_batch: too many rays for one launch");
     dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-    const uint32_t lds_entries = s->deep && s->stack_depth > s->lds_stack ? s->lds_stack : s->stack_depth;  // deep trees: the rest in private memory
+    uint32_t lds_entries = s->deep && s->stack_depth > s->lds_stack ? s->lds_stack : s->stack_depth;  // deep trees: the rest in private memory
+    if (s->deep) {  // four waves share the block's LDS request: keep it inside 64 KB whatever split the caller chose
+        const uint32_t most = (65536u - (kBlock / 64) * kCoopBytesPerWave) / (kBlock * (uint32_t)sizeof(uint32_t));
+        if (lds_entries > most) lds_entries = most;
+    }
     size_t lds = (size_t)kBlock * lds_entries * sizeof(uint32_t) + (size_t)(kBlock / 64) * (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave);
     hipStream_t st = (hipStream_t)stream;
     if (s->clean)
