@@ -352,8 +352,8 @@ __global__ void k_accumulate(const float* __restrict__ slab, uint32_t n_samples,
     rgb_sum[i] = sum;
 }
 
-// ≙ Aggregate::hit (aggregate.rs:118-124) for a batch of rays, one lane per ray.
-template <int AABB_MODE, bool DEEP>
+// ≙ Aggregate::hit (aggregate.rs:118-124) for a batch of rays on a shallow tree, one lane per ray.
+template <int AABB_MODE>
 __global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, const float* __restrict__ o, const float* __restrict__ d, size_t n, float t_min,
                                                       float t_max, uint32_t seed, uint32_t stack_depth, int* __restrict__ prim, float* __restrict__ t_hit) {
     extern __shared__ uint32_t lds_stack[];
@@ -366,19 +366,81 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, const float* __
         r.d = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
     }
     Rng g = rng_seed(seed, (uint32_t)i, 0);
-    Hit h;
-    if (DEEP) {
-        unsigned char* coop = (unsigned char*)(lds_stack + kBlock * stack_depth) + (threadIdx.x >> 6) * kCoopBytesPerWave;
-        uint32_t beyond[kMaxStackDepth];  // private memory: stack entries past the stack_depth ones kept in LDS
-        const WalkStack stack = {lds_stack + threadIdx.x, kBlock, stack_depth, beyond};
-        h = closest_hit_deep<AABB_MODE, F_ALL>(sc, active, r, t_min, t_max, g, 0, stack, coop);
-    } else {
-        unsigned char* area = (unsigned char*)(lds_stack + kBlock * stack_depth) + (threadIdx.x >> 6) * kSiftBytesPerWave;
-        h = closest_hit_sift<AABB_MODE, F_ALL>(sc, active, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock, area);
-    }
+    unsigned char* area = (unsigned char*)(lds_stack + kBlock * stack_depth) + (threadIdx.x >> 6) * kSiftBytesPerWave;
+    const Hit h = closest_hit_sift<AABB_MODE, F_ALL>(sc, active, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock, area);
     if (!active) return;
     prim[i] = h.slot >= 0 ? (int)__float_as_uint(sc.slots[3 * h.slot].w) : -1;
     t_hit[i] = h.t;
+}
+
+// The same for deep trees, on the schedule of k_trace_stream without the shading: a wave owns a run of consecutive rays, and a
+// lane whose query has ended writes its answer and fetches the next ray of the run at once (FRESH / READY lanes are served
+// when 16 of them wait), so no lane idles until the slowest query of the wave is through.
+template <int AABB_MODE>
+__global__ __launch_bounds__(kTraceBlock) void k_intersect_stream(DScene sc, const float* __restrict__ o, const float* __restrict__ d, size_t n, float t_min,
+                                                                  float t_max, uint32_t seed, uint32_t lds_entries, uint32_t run, uint32_t coop_lanes,
+                                                                  int* __restrict__ prim, float* __restrict__ t_hit) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t lane = threadIdx.x;
+    const size_t first = (size_t)blockIdx.x * run;
+    const uint32_t pool = n - first < (size_t)run ? (uint32_t)(n - first) : run;
+    uint32_t beyond[kMaxStackDepth];  // private memory: stack entries past the lds_entries ones kept in LDS
+    const WalkStack stack = {lds_stack + lane, kTraceBlock, lds_entries, beyond};
+    unsigned char* coop = (unsigned char*)(lds_stack + kTraceBlock * lds_entries);
+    enum : uint32_t { DEAD = 0, FRESH = 1, WALK = 2, LEAF = 3, READY = 4 };
+    uint32_t next = 64u;  // next unfetched ray of the run (wave-uniform)
+    uint32_t idx = lane;
+    uint32_t st = idx < pool ? FRESH : DEAD;
+    Ray r;
+    r.o = r.d = mk3(0.0f, 0.0f, 1.0f);
+    Rng g;
+    g.s0 = g.s1 = 0;
+    Walk w;
+    walk_begin(sc, w, false, r, t_max);
+    for (;;) {
+        const unsigned long long walking = RRT_BALLOT(st == WALK), paused = RRT_BALLOT(st == LEAF), waiting = RRT_BALLOT(st == READY || st == FRESH);
+        if ((walking | paused | waiting) == 0ull) break;
+        if (waiting != 0ull && ((uint32_t)__popcll(waiting) >= 16u || (walking | paused) == 0ull)) {
+            const bool done = st == READY;
+            if (done) {
+                const size_t i = first + idx;
+                prim[i] = w.h.slot >= 0 ? (int)__float_as_uint(sc.slots[3 * w.h.slot].w) : -1;
+                t_hit[i] = w.h.t;
+            }
+            const unsigned long long finished = RRT_BALLOT(done);
+            if (done) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(finished >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)finished, 0u));
+                idx = next + rank;
+                st = idx < pool ? FRESH : DEAD;
+            }
+            next += (uint32_t)__popcll(finished);
+            if (st == FRESH) {
+                const size_t i = first + idx;
+                r.o = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+                r.d = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+                g = rng_seed(seed, (uint32_t)i, 0);
+                walk_begin(sc, w, true, r, t_max);
+                st = w.running ? WALK : READY;  // an empty scene answers at once
+            }
+            continue;
+        }
+#pragma unroll 1
+        for (int rep = 0; rep < kWalkSteps; ++rep) {
+            if (st == WALK) {
+                walk_step<AABB_MODE>(sc, w, r, t_min, stack);
+                if (w.pending) st = LEAF;
+                else if (!w.running) st = READY;
+            }
+        }
+        const unsigned long long at_leaf = RRT_BALLOT(st == LEAF);
+        if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
+            coop_leaves<F_ALL, AABB_MODE == kAabbClean>(sc, r, t_min, g, 0, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
+            if (st == LEAF) {
+                walk_resume(w, stack);
+                st = w.running ? WALK : READY;
+            }
+        }
+    }
 }
 
 // ≙ main.rs:173-186
@@ -487,7 +549,7 @@ struct rrt_scene {
     uint32_t res_x = 0, res_y = 0, samples = 0, stack_depth = 1;
     uint32_t lds_stack = kLdsStackEntries;  // deep trees: stack entries per lane that k_trace_stream keeps in LDS
     uint32_t features = 0;  // F_* bits the scene needs
-    bool deep = false;      // many-node tree: kernels use the cooperative-leaf walk (closest_hit_deep)
+    bool deep = false;      // many-node tree: the streaming kernels (per-lane walk, cooperative leaf phases)
     bool clean = false;     // tree built with RRT_AGGREGATE_BVH_CLEAN: traversal mode kAabbClean, whatever the caller asks for
     bool harvest = false;   // single leaf, 1..kHarvestLights lights, each one a primitive of the leaf: light densities come out of the closest-hit query
     uint32_t n_spheres = 0, n_media = 0, n_btris = 0, n_materials = 0, n_textures = 0;
@@ -1016,22 +1078,27 @@ int rrt_intersect_batch_device(rrt_scene* s, const float* d_o, const float* d_d,
     if (int rc = check_device(s)) return rc;
     if (n == 0) return RRT_OK;
     if (n > (size_t)0x7fffffff * kBlock) return rrt_set_error(RRT_ERR_LIMIT, "rrt_intersect_batch: too many rays for one launch");
-    dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
-    uint32_t lds_entries = s->deep && s->stack_depth > s->lds_stack ? s->lds_stack : s->stack_depth;  // deep trees: the rest in private memory
-    if (s->deep) {  // four waves share the block's LDS request: keep it inside 64 KB whatever split the caller chose
-        const uint32_t most = (65536u - (kBlock / 64) * kCoopBytesPerWave) / (kBlock * (uint32_t)sizeof(uint32_t));
-        if (lds_entries > most) lds_entries = most;
-    }
-    size_t lds = (size_t)kBlock * lds_entries * sizeof(uint32_t) + (size_t)(kBlock / 64) * (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave);
     hipStream_t st = (hipStream_t)stream;
-    if (s->clean)
-        hipLaunchKernelGGL((k_intersect<kAabbClean, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, d_prim, d_t);
-    else if (aabb_mode == RRT_AABB_REFERENCE)
-        if (s->deep) hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, d_prim, d_t);
-        else hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE, false>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, d_prim, d_t);
-    else
-        if (s->deep) hipLaunchKernelGGL((k_intersect<RRT_AABB_TIGHT, true>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, d_prim, d_t);
-        else hipLaunchKernelGGL((k_intersect<RRT_AABB_TIGHT, false>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, d_prim, d_t);
+    if (s->deep) {
+        // a run of up to 1024 rays per wave (16 per lane to refill from), shorter while the batch has fewer than 16384 runs
+        uint32_t run = 1024;
+        while (run > 64u && (n + run - 1) / run < 16384u) run /= 2u;
+        const uint32_t lds_entries = s->stack_depth > s->lds_stack ? s->lds_stack : s->stack_depth;  // the rest in private memory
+        const size_t lds = (size_t)kTraceBlock * lds_entries * sizeof(uint32_t) + kCoopBytesPerWave;
+        const dim3 grid((unsigned)((n + run - 1) / run));
+#define RRT_LAUNCH_BATCH(MODE) hipLaunchKernelGGL((k_intersect_stream<MODE>), grid, dim3(kTraceBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, run, 24u, d_prim, d_t)
+        if (s->clean) RRT_LAUNCH_BATCH(kAabbClean);
+        else if (aabb_mode == RRT_AABB_REFERENCE) RRT_LAUNCH_BATCH(RRT_AABB_REFERENCE);
+        else RRT_LAUNCH_BATCH(RRT_AABB_TIGHT);
+#undef RRT_LAUNCH_BATCH
+    } else {
+        const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
+        const size_t lds = (size_t)kBlock * s->stack_depth * sizeof(uint32_t) + (size_t)(kBlock / 64) * kSiftBytesPerWave;
+        if (aabb_mode == RRT_AABB_REFERENCE)
+            hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
+        else
+            hipLaunchKernelGGL((k_intersect<RRT_AABB_TIGHT>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
+    }
     HIP_TRY(hipGetLastError());
     return RRT_OK;
 }

@@ -194,10 +194,6 @@ RRT_DEV float ord_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ?
 //
 // `coop` is this wave's LDS area: 64 x u64 keys followed by 64 x (slot, det, u, v).
 constexpr uint32_t kCoopBytesPerWave = 64 * 8 + 64 * 16 + 128 * 4;  // closest keys, hit payloads, item list
-#ifndef RRT_COOP_LANES
-#define RRT_COOP_LANES 8
-#endif
-constexpr uint32_t kCoopLanes = RRT_COOP_LANES;  // paused lanes that trigger a cooperative leaf phase
 
 // Tests up to 64 listed (owner lane, pair position) items, one per lane, for coop_leaves().
 template <uint32_t FEAT, bool CLEAN>
@@ -418,45 +414,6 @@ RRT_DEV void walk_resume(Walk& w, const WalkStack& stack) {
         w.cur = stack_pop(stack, w.sp);
         w.running = true;
     }
-}
-
-template <int AABB_MODE, uint32_t FEAT>
-RRT_DEV Hit closest_hit_deep(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, const WalkStack& stack,
-                             unsigned char* coop) {
-    // Must be called by all 64 lanes of the wave (the cooperative phase addresses lanes by number); lanes without a ray
-    // pass active = false and only lend a hand.
-    Walk w;
-    walk_begin(sc, w, active, r, t_max);
-#ifdef RRT_PHASE_PROFILE
-    unsigned long long prof_nodes = 0, prof_pairs = 0, prof_steps = 0, prof_leaf_steps = 0;
-#endif
-    for (;;) {
-        if (w.running) {
-            RRT_COUNT(prof_nodes, 1);
-            walk_step<AABB_MODE>(sc, w, r, t_min, stack);
-            if (w.pending) RRT_COUNT(prof_pairs, w.n_pairs);
-        }
-        const unsigned long long waiting = RRT_BALLOT(w.pending), walking = RRT_BALLOT(w.running);
-#ifdef RRT_PHASE_PROFILE
-        if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_steps;
-#endif
-        if (waiting != 0ull && ((uint32_t)__popcll(waiting) >= kCoopLanes || walking == 0ull)) {
-#ifdef RRT_PHASE_PROFILE
-            if ((int)(threadIdx.x & 63u) == __ffsll((long long)__ballot(true)) - 1) ++prof_leaf_steps;
-#endif
-            coop_leaves<FEAT, AABB_MODE == kAabbClean>(sc, r, t_min, key, depth, w.pending, w.first_pair, w.n_pairs, w.h, coop);
-            if (w.pending) walk_resume(w, stack);
-        } else if (waiting == 0ull && walking == 0ull) {
-            break;
-        }
-    }
-#ifdef RRT_PHASE_PROFILE
-    atomicAdd(&g_prof[0], prof_nodes);
-    atomicAdd(&g_prof[1], prof_pairs);
-    atomicAdd(&g_prof[2], prof_steps);
-    atomicAdd(&g_prof[3], prof_leaf_steps);
-#endif
-    return w.h;
 }
 
 // Recomputes (u, v, det) the way Triangle::get_hit_properties does (shape.rs:384-400) for callers without a Hit.

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Throughput of rrt_intersect_batch_device (Aggregate::hit for a ray batch): python tools/perf_intersect.py [scene.json] [n_rays]"""
+"""Throughput of rrt_intersect_batch_device (Aggregate::hit for a ray batch): python tools/perf_intersect.py [scene.json|mesh=N[,clean]] [n_rays]
+(mesh=N: the synthetic displaced grid of 2*N*N triangles, random rays from above it)"""
 import os
 import sys
 
@@ -15,10 +16,19 @@ import rust_raytracer_amd as rrt
 name = sys.argv[1] if len(sys.argv) > 1 else "Cornell_Box_With_Sphere.json"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 1 << 24
 torch.cuda.set_device(0)
-sc = rrt.Scene.load(os.path.join(ROOT, "tests", "golden", "assets", name))
 g = torch.Generator(device="cuda").manual_seed(1)
-o = torch.rand((n, 3), device="cuda", generator=g) * 500.0 + 20.0
-d = torch.randn((n, 3), device="cuda", generator=g)
+if name.startswith("mesh="):
+    import synth
+    spec = name[5:].split(",")
+    sc = rrt.Scene(synth.host_scene(synth.terrain_desc(int(spec[0])), "BVH_CLEAN" if "clean" in spec else "BVH_GPU"))
+    o = torch.rand((n, 3), device="cuda", generator=g) * 2.0 - 1.0
+    o[:, 1] = o[:, 1] * 0.25 + 0.6  # a slab above the terrain
+    d = torch.randn((n, 3), device="cuda", generator=g)
+    d[:, 1] = -d[:, 1].abs() * 0.5  # looking down at all angles
+else:
+    sc = rrt.Scene.load(os.path.join(ROOT, "tests", "golden", "assets", name))
+    o = torch.rand((n, 3), device="cuda", generator=g) * 500.0 + 20.0
+    d = torch.randn((n, 3), device="cuda", generator=g)
 prim = torch.empty(n, dtype=torch.int32, device="cuda")
 t = torch.empty(n, dtype=torch.float32, device="cuda")
 L = rrt.lib()
