@@ -186,6 +186,13 @@ def test_mesh_with_a_deep_tree_bit_exact(gpu, cull):
         same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
         assert same.all(), "%d of %d values differ (mode %d)" % ((~same).sum(), same.size, mode)
         assert st["rays"] == int(st_ref[0])
+    if cull is False:
+        # a batch large enough for the ray-batch kernel to give every wave a run of several rays per lane (lanes fetch the
+        # next ray when their query ends), with a ragged end: the same rays over and over must give the same answers
+        reps = 2_200_000 // len(ro) + 1
+        big_o, big_d = np.tile(ro, (reps, 1))[:-37], np.tile(rd, (reps, 1))[:-37]
+        p, t = g.hit(big_o, big_d)
+        assert np.array_equal(p, np.tile(p_ref, reps)[:-37]) and np.array_equal(bits(t), bits(np.tile(t_ref, reps)[:-37]))
 
 
 @pytest.mark.parametrize("media", [0, 6])
