@@ -200,7 +200,11 @@ template <int AABB_MODE, uint32_t FEAT>
 __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stream(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t lane = threadIdx.x;
-    const uint32_t chunk = blockIdx.x / ta.n_t8, j = blockIdx.x % ta.n_t8;
+    // Workgroups go to the eight XCDs (each with an L2 of its own) round-robin by number.  Renumbered in groups of 128, the
+    // sixteen 8x8 tiles of one 32x32 tile land on ONE XCD, neighbouring 32x32 tiles on neighbouring XCDs (balance stays fine-grained).
+    uint32_t item = blockIdx.x;
+    if (item < (gridDim.x & ~127u)) item = (((item >> 7) * 8u + (item & 7u)) << 4) | ((item >> 3) & 15u);
+    const uint32_t chunk = item / ta.n_t8, j = item % ta.n_t8;
     const uint32_t tile32 = ta.tile_index + (j >> 4) * ta.tile_count;
     const uint32_t x0 = (tile32 % ta.tiles_x) * 32u + ((j & 3u) << 3);
     const uint32_t y0 = (tile32 / ta.tiles_x) * 32u + (((j >> 2) & 3u) << 3);
