@@ -16,6 +16,10 @@ namespace rrt_host {
 
 namespace {
 
+// Largest image either decoder accepts (16384 x 16384): keeps every size computation far inside size_t and the
+// allocations bounded for files whose headers lie.
+constexpr uint64_t kMaxImagePixels = 1ull << 28;
+
 struct Huff {
     // canonical code tables: for each code length, the smallest code and the index of its first symbol
     int mincode[17], maxcode[18], valptr[17];
@@ -109,8 +113,8 @@ void idct_block(const int* coef, const uint16_t* quant, uint8_t* out, int stride
             long z1 = (z2 + z3) * F_0_541;
             long t2 = z1 + z3 * (-F_1_847);
             long t3 = z1 + z2 * F_0_765;
-            long t0 = (in[0] + in[4]) << CB;
-            long t1 = (in[0] - in[4]) << CB;
+            long t0 = (in[0] + in[4]) * (1L << CB);  // (a shift of a negative value is undefined before C++20)
+            long t1 = (in[0] - in[4]) * (1L << CB);
             long t10 = t0 + t3, t13 = t0 - t3, t11 = t1 + t2, t12 = t1 - t2;
             t0 = in[7]; t1 = in[5]; t2 = in[3]; t3 = in[1];
             z1 = t0 + t3; z2 = t1 + t2; z3 = t0 + t2;
@@ -192,11 +196,18 @@ std::string decode_jpeg(const std::vector<uint8_t>& f, uint32_t* w, uint32_t* h,
                 t.present = true;
             }
         } else if (marker == 0xC0 || marker == 0xC1) {  // baseline / extended sequential, Huffman
+            if (len < 8) return "JPEG: truncated frame header";
             if (f[seg] != 8) return "JPEG: only 8-bit samples are supported";
             height = be16(seg + 1);
             width = be16(seg + 3);
             ncomp = f[seg + 5];
             if (width <= 0 || height <= 0 || (ncomp != 1 && ncomp != 3)) return "JPEG: unsupported frame";
+            if (len < 8 + 3 * ncomp) return "JPEG: truncated frame header";
+            if ((uint64_t)width * (uint64_t)height > kMaxImagePixels) return "JPEG: image too large";
+            // An 8x8 block costs at least two bits of entropy-coded data (a one-bit DC code and a one-bit end-of-block), so a
+            // file of n bytes describes at most 256 n pixels: a frame header that claims more is lying, and is refused before
+            // any plane is allocated.
+            if ((uint64_t)width * (uint64_t)height > (uint64_t)f.size() * 256u) return "JPEG: frame larger than the file's data can describe";
             for (int c = 0; c < ncomp; ++c) {
                 comp[c].id = f[seg + 6 + 3 * c];
                 comp[c].h = f[seg + 7 + 3 * c] >> 4;
@@ -208,11 +219,14 @@ std::string decode_jpeg(const std::vector<uint8_t>& f, uint32_t* w, uint32_t* h,
         } else if (marker == 0xC2) {
             return "JPEG: progressive files are not supported";
         } else if (marker == 0xDD) {
+            if (len < 4) return "JPEG: truncated restart interval";
             restart_interval = be16(seg);
         } else if (marker == 0xDA) {  // start of scan: decode the whole (single, interleaved) scan
             if (!have_frame) return "JPEG: scan before frame";
+            if (len < 3) return "JPEG: truncated scan header";
             int ns = f[seg];
             if (ns != ncomp) return "JPEG: multi-scan files are not supported";
+            if (len < 6 + 2 * ns) return "JPEG: truncated scan header";
             for (int k = 0; k < ns; ++k) {
                 int cid = f[seg + 1 + 2 * k];
                 for (int c = 0; c < ncomp; ++c)
@@ -221,6 +235,8 @@ std::string decode_jpeg(const std::vector<uint8_t>& f, uint32_t* w, uint32_t* h,
                         comp[c].ta = f[seg + 2 + 2 * k] & 15;
                     }
             }
+            for (int c = 0; c < ncomp; ++c)
+                if (comp[c].td > 3 || comp[c].ta > 3) return "JPEG: bad Huffman table id in scan";
             int hmax = 1, vmax = 1;
             for (int c = 0; c < ncomp; ++c) {
                 hmax = comp[c].h > hmax ? comp[c].h : hmax;
@@ -340,13 +356,16 @@ std::string decode_png(const std::vector<uint8_t>& f, uint32_t* w, uint32_t* h, 
         i += 12 + (size_t)len;
     }
     if (width == 0 || height == 0) return "PNG: missing IHDR";
+    if ((uint64_t)width * (uint64_t)height > kMaxImagePixels) return "PNG: image too large";
     if (interlace) return "PNG: interlaced files are not supported";
     int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!samples || (depth != 8 && depth != 16 && !((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))))
         return "PNG: unsupported colour type / bit depth";
     size_t bpp_bits = (size_t)samples * depth;
-    size_t row_bytes = (width * bpp_bits + 7) / 8;
+    size_t row_bytes = ((size_t)width * bpp_bits + 7) / 8;
     size_t bpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;
+    // deflate expands by at most a factor of 1032, so the header's size can be checked against the data before allocating
+    if ((uint64_t)(row_bytes + 1) * height > (uint64_t)idat.size() * 1032u + 1024u) return "PNG: image larger than its data can describe";
     std::vector<uint8_t> raw((row_bytes + 1) * height);
     uLongf raw_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return "PNG: inflate failed";
@@ -389,7 +408,7 @@ std::string decode_png(const std::vector<uint8_t>& f, uint32_t* w, uint32_t* h, 
             uint8_t* q = &(*px)[((size_t)y * width + x) * *channels];
             if (ctype == 3) {
                 size_t pi = (size_t)s[0] * 3;
-                if (pi + 2 >= palette.size() + 0 && pi + 3 > palette.size()) return "PNG: palette index out of range";
+                if (pi + 3 > palette.size()) return "PNG: palette index out of range";
                 q[0] = palette[pi]; q[1] = palette[pi + 1]; q[2] = palette[pi + 2];
             } else if (*channels == 1) {
                 q[0] = s[0];

@@ -7,6 +7,7 @@
 #include <cstdio>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <numeric>
 
 #include "../rrt_error.hpp"
@@ -416,8 +417,10 @@ extern "C" {
 
 int rrt_host_scene_new(rrt_host_scene** out) {
     RRT_NEED(out);
-    *out = new rrt_host_scene();
-    return RRT_OK;
+    return rrt_guard("rrt_host_scene_new", [&]() -> int {
+        *out = new rrt_host_scene();
+        return RRT_OK;
+    });
 }
 void rrt_host_scene_destroy(rrt_host_scene* s) { delete s; }
 
@@ -427,41 +430,50 @@ int rrt_host_scene_load(const char* path, uint32_t ow, uint32_t oh, uint32_t os,
 int rrt_host_scene_load_as(const char* path, uint32_t ow, uint32_t oh, uint32_t os, float oaspect, int tree, rrt_host_scene** out) {
     RRT_NEED(path && out);
     RRT_NEED(tree == RRT_AGGREGATE_BVH || tree == RRT_AGGREGATE_BVH_GPU || tree == RRT_AGGREGATE_BVH_CLEAN);
-    rrt_host_scene* s = new rrt_host_scene();
-    std::string e = rrt_host::load_scene_file(path, ow, oh, os, oaspect, tree, &s->b);
-    if (!e.empty()) {
-        delete s;
-        return fail_scene(e);
-    }
-    *out = s;
-    return RRT_OK;
+    return rrt_guard("rrt_host_scene_load", [&]() -> int {
+        std::unique_ptr<rrt_host_scene> s(new rrt_host_scene());
+        std::string e = rrt_host::load_scene_file(path, ow, oh, os, oaspect, tree, &s->b);
+        if (!e.empty()) return fail_scene(e);
+        *out = s.release();
+        return RRT_OK;
+    });
 }
 int rrt_host_add_texture(rrt_host_scene* s, const rrt_texture* t, const uint8_t* texels, int32_t* id) {
     RRT_NEED(s && t);
-    std::string e = s->b.add_texture(*t, texels, id);
-    return e.empty() ? RRT_OK : fail_scene(e);
+    return rrt_guard("rrt_host_add_texture", [&]() -> int {
+        std::string e = s->b.add_texture(*t, texels, id);
+        return e.empty() ? RRT_OK : fail_scene(e);
+    });
 }
 int rrt_host_add_material(rrt_host_scene* s, uint32_t type, int32_t albedo, int32_t bump, float param, int32_t* id) {
     RRT_NEED(s);
-    std::string e = s->b.add_material(type, albedo, bump, param, id);
-    return e.empty() ? RRT_OK : fail_scene(e);
+    return rrt_guard("rrt_host_add_material", [&]() -> int {
+        std::string e = s->b.add_material(type, albedo, bump, param, id);
+        return e.empty() ? RRT_OK : fail_scene(e);
+    });
 }
 int rrt_host_add_sphere(rrt_host_scene* s, const float* tr, const float* rot, const float* scl, float radius, int32_t material) {
     RRT_NEED(s && tr && rot && scl);
-    std::string e = s->b.add_sphere(v3p(tr), v3p(rot), v3p(scl), radius, material);
-    return e.empty() ? RRT_OK : fail_scene(e);
+    return rrt_guard("rrt_host_add_sphere", [&]() -> int {
+        std::string e = s->b.add_sphere(v3p(tr), v3p(rot), v3p(scl), radius, material);
+        return e.empty() ? RRT_OK : fail_scene(e);
+    });
 }
 int rrt_host_add_mesh(rrt_host_scene* s, const float* tr, const float* rot, const float* scl, uint32_t nv, const double* v, uint32_t nt,
                       const double* t, uint32_t ntri, const int32_t* vidx, const int32_t* tidx, int cull, int32_t material) {
     RRT_NEED(s && tr && rot && scl && (nv == 0 || v) && (ntri == 0 || vidx));
-    std::string e = s->b.add_mesh(v3p(tr), v3p(rot), v3p(scl), nv, v, nt, t, ntri, vidx, tidx, cull != 0, material, false);
-    return e.empty() ? RRT_OK : fail_scene(e);
+    return rrt_guard("rrt_host_add_mesh", [&]() -> int {
+        std::string e = s->b.add_mesh(v3p(tr), v3p(rot), v3p(scl), nv, v, nt, t, ntri, vidx, tidx, cull != 0, material, false);
+        return e.empty() ? RRT_OK : fail_scene(e);
+    });
 }
 int rrt_host_add_medium_sphere(rrt_host_scene* s, const float* tr, const float* rot, const float* scl, float radius, int32_t bmat, float density,
                                int32_t phase) {
     RRT_NEED(s && tr && rot && scl);
-    std::string e = s->b.add_medium_sphere(v3p(tr), v3p(rot), v3p(scl), radius, bmat, density, phase);
-    return e.empty() ? RRT_OK : fail_scene(e);
+    return rrt_guard("rrt_host_add_medium_sphere", [&]() -> int {
+        std::string e = s->b.add_medium_sphere(v3p(tr), v3p(rot), v3p(scl), radius, bmat, density, phase);
+        return e.empty() ? RRT_OK : fail_scene(e);
+    });
 }
 int rrt_host_set_camera(rrt_host_scene* s, const float* pos, const float* look, const float* up, float fov, float aspect, float aperture,
                         float focus) {
@@ -477,8 +489,10 @@ int rrt_host_set_logistics(rrt_host_scene* s, uint32_t rx, uint32_t ry, uint32_t
 int rrt_host_finalize(rrt_host_scene* s, int aggregate) {
     RRT_NEED(s);
     RRT_NEED(aggregate >= RRT_AGGREGATE_LIST && aggregate <= RRT_AGGREGATE_BVH_CLEAN);
-    std::string e = s->b.finalize(aggregate);
-    return e.empty() ? RRT_OK : fail_scene(e);
+    return rrt_guard("rrt_host_finalize", [&]() -> int {
+        std::string e = s->b.finalize(aggregate);
+        return e.empty() ? RRT_OK : fail_scene(e);
+    });
 }
 const rrt_scene_desc* rrt_host_desc(const rrt_host_scene* s) {
     if (!s || !s->b.finalized) {

@@ -6,6 +6,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -28,6 +29,7 @@ constexpr uint32_t kMaxStackDepth = 64;  // traversal stack: entries per lane
 constexpr uint32_t kLdsStackEntries = 32;  // k_trace_stream keeps this many of them in LDS (10 KB per wave with the cooperative area: 16 waves
                                            // per compute unit), the rest in private memory
 constexpr uint32_t kDeepTreeNodes = 16;  // trees with more nodes than this take the cooperative-leaf walk
+constexpr size_t kMaxTimedPasses = 4096;   // render passes whose events a scene handle keeps between two rrt_scene_kernel_times calls
 constexpr size_t kSlabCapBytes = 16ull << 30;  // default budget of the per-sample radiance staging buffer (per scene handle, per GPU):
                                                // sized for 288 GB of HBM, so that a 1024x1024 frame at 1024 spp is a single pass
 
@@ -564,7 +566,7 @@ struct rrt_scene {
     size_t events_used = 0;          // multiples of three
 };
 
-static int validate_desc(const rrt_scene_desc* d) {
+static int validate_desc(const rrt_scene_desc* d, uint32_t* tree_depth) {
 #define BAD(msg) return rrt_set_error(RRT_ERR_INVALID, std::string("scene description: ") + msg)
     if (d->n_nodes && !d->nodes) BAD("nodes is NULL");
     if (d->n_slots && (!d->slots || !d->tri_shade)) BAD("slots/tri_shade is NULL");
@@ -624,14 +626,20 @@ static int validate_desc(const rrt_scene_desc* d) {
         if (l.kind == RRT_KIND_SPHERE) { if (l.index >= d->n_spheres) BAD("light sphere out of range"); }
         else if (l.kind != RRT_KIND_TRIANGLE) BAD("unknown light kind");
     }
-    // The traversal stack is sized from the tree itself, never from a number the caller supplies.
+    // The traversal stack is sized from the tree itself, never from a number the caller supplies.  The walk also proves that the
+    // links form a tree: every node is reached exactly once (a node with two parents would make this walk, and the bottom-up
+    // box pass, exponential; an unreachable one has no place in a pre-order layout).
     {
         std::vector<std::pair<uint32_t, uint32_t>> todo;  // (node, inner ancestors)
-        uint32_t deepest = 0;
+        std::vector<bool> seen(d->n_nodes, false);
+        uint32_t deepest = 0, reached = 0;
         if (d->n_nodes) todo.emplace_back(0u, 0u);
         while (!todo.empty()) {
             auto [i, depth] = todo.back();
             todo.pop_back();
+            if (seen[i]) BAD("a node is the child of two nodes");
+            seen[i] = true;
+            ++reached;
             if (depth > deepest) deepest = depth;
             const rrt_node& n = d->nodes[i];
             if (!(n.b & RRT_LEAF_FLAG)) {
@@ -639,8 +647,10 @@ static int validate_desc(const rrt_scene_desc* d) {
                 todo.emplace_back(n.a, depth + 1);
             }
         }
+        if (reached != d->n_nodes) BAD("a node is not reachable from the root");
         if (deepest + 1 > kMaxStackDepth) return rrt_set_error(RRT_ERR_LIMIT, "BVH needs more than 64 pending stack entries per ray");
         if (d->bvh_depth < deepest + 1) BAD("bvh_depth is smaller than the tree requires");
+        *tree_depth = deepest + 1;
     }
 #undef BAD
     return RRT_OK;
@@ -731,17 +741,21 @@ static std::vector<float> tight_boxes(const rrt_scene_desc* d) {
     return tb;
 }
 
-int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
+static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     if (!desc || !out) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_create: NULL argument");
-    int rc = validate_desc(desc);
+    uint32_t tree_depth = 1;
+    int rc = validate_desc(desc, &tree_depth);
     if (rc) return rc;
-    rrt_scene* s = new rrt_scene();
+    // owns the handle (and through rrt_scene_destroy its device buffers) until the last step has succeeded
+    struct Destroy { void operator()(rrt_scene* p) const { rrt_scene_destroy(p); } };
+    std::unique_ptr<rrt_scene, Destroy> owner(new rrt_scene());
+    rrt_scene* s = owner.get();
     HIP_TRY(hipGetDevice(&s->device));
     uint32_t clean_depth = 0;  // clean trees: most stack entries a walk can have pending (sizes the traversal stack)
 #define UP(field, src, count)                                                        \
     do {                                                                             \
         rc = upload(src, count, (const void**)&s->d.field, &s->owned);               \
-        if (rc) { rrt_scene_destroy(s); return rc; }                                 \
+        if (rc) return rc;                                                           \
     } while (0)
     // Device copy of the tree: leaves reference pair records (two primitives interleaved component-wise plus their box,
     // 128 bytes).  Which primitives share a record is free (every comparison on the device orders hits by distance, then
@@ -885,7 +899,8 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             };
             auto link_of = [&](const Child& c, uint32_t* out_link) -> bool {  // true when the child is a leaf small enough for a direct link
                 if (!c.is_range || c.count > 8) return false;
-                *out_link = kLinkLeaf | ((c.count - 1u) << 28) | c.first;
+                // a leaf without shapes (the description may hold one) gets the link of an unused place: nothing to fetch
+                *out_link = c.count == 0u ? kLinkNone : (kLinkLeaf | ((c.count - 1u) << 28) | c.first);
                 return true;
             };
             auto split = [&](const Child& c, Child* out) {
@@ -908,10 +923,8 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                 for (int k = 24; k < 28; ++k) rec[at + k] = put_u(kLinkNone);
                 return (uint32_t)(at / 32);
             };
-            if ((uint64_t)pairs.size() / (4 * kPairQuads) >= 0x0fffffffull) {  // keeps every leaf link apart from kLinkNone
-                rrt_scene_destroy(s);
+            if ((uint64_t)pairs.size() / (4 * kPairQuads) >= 0x0fffffffull)  // keeps every leaf link apart from kLinkNone
                 return rrt_set_error(RRT_ERR_LIMIT, "clean tree: more than 2^28 - 2 pair records");
-            }
             struct Pending { Child c; uint32_t self, above; };  // above: stack entries that can be pending when the walk reaches this node
             std::vector<Pending> todo;
             uint32_t root_link = 0;
@@ -958,10 +971,7 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                 }
             }
             s->d.root_link = root_link;
-            if (clean_depth + 1u > kMaxStackDepth) {
-                rrt_scene_destroy(s);
-                return rrt_set_error(RRT_ERR_LIMIT, "clean tree needs more than 64 pending stack entries per ray");
-            }
+            if (clean_depth + 1u > kMaxStackDepth) return rrt_set_error(RRT_ERR_LIMIT, "clean tree needs more than 64 pending stack entries per ray");
             UP(nodes, (const float4*)rec.data(), rec.size() / 4);
         } else {
             std::vector<float> rec((size_t)dn.size() * 16);  // node (32 bytes) + primitive box (32 bytes) per 64-byte record
@@ -972,10 +982,8 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             UP(nodes, (const float4*)rec.data(), rec.size() / 4);
         }
         // the sifting traversal of shallow trees packs (pair, lane) into 32 bits
-        if (!clean && desc->n_nodes <= kDeepTreeNodes && pairs.size() / (4 * kPairQuads) > (1u << 25)) {
-            rrt_scene_destroy(s);
+        if (!clean && desc->n_nodes <= kDeepTreeNodes && pairs.size() / (4 * kPairQuads) > (1u << 25))
             return rrt_set_error(RRT_ERR_LIMIT, "a tree of at most 16 nodes (or a List) with more than 2^25 pair records");
-        }
         UP(pairs, (const float4*)pairs.data(), pairs.size() / 4);
     }
     UP(slots, (const float4*)desc->slots, (size_t)desc->n_slots * 3);
@@ -998,7 +1006,7 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     s->res_x = desc->resolution_x;
     s->res_y = desc->resolution_y;
     s->samples = desc->samples;
-    s->stack_depth = desc->bvh_depth ? desc->bvh_depth : 1;
+    s->stack_depth = tree_depth;  // what validate_desc measured on the tree, not the caller's bvh_depth (which may only be larger)
     if (desc->aggregate_kind == RRT_AGGREGATE_BVH_CLEAN) s->stack_depth = clean_depth + 1u;
     s->n_textures = desc->n_textures;
     s->deep = desc->n_nodes > kDeepTreeNodes || s->clean;  // the clean mode's tie rule lives in the cooperative-leaf walk only
@@ -1016,8 +1024,12 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         if (desc->materials[i].bump >= 0) s->features |= F_BUMP | F_TEX;
         if (desc->materials[i].type == RRT_MAT_ISOTROPIC) s->features |= F_MEDIUM;
     }
-    *out = s;
+    *out = owner.release();
     return RRT_OK;
+}
+
+int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
+    return rrt_guard("rrt_scene_create", [&]() -> int { return scene_create(desc, out); });
 }
 
 int rrt_scene_set_staging_limit(rrt_scene* s, uint64_t bytes) {
@@ -1207,7 +1219,7 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
     unsigned long long* cnt = (unsigned long long*)d_counters;
     for (uint32_t done = 0; done < plan.spp; done += (uint32_t)per_pass) {
         hipEvent_t* ev = nullptr;
-        if (s->timing) {
+        if (s->timing && s->events_used + 3 <= kMaxTimedPasses * 3) {  // passes beyond the cap run untimed until rrt_scene_kernel_times is called
             while (s->events.size() < s->events_used + 3) {
                 hipEvent_t e;
                 HIP_TRY(hipEventCreate(&e));

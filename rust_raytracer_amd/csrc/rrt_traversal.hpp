@@ -323,7 +323,7 @@ RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, fl
     w.cur = sc.root_link;  // 0 for the reference's trees
     w.pending = false;
     w.first_pair = w.n_pairs = 0;
-    w.running = active && sc.n_nodes != 0;
+    w.running = active && sc.n_nodes != 0 && w.cur != kLinkNone;  // kLinkNone: a clean tree whose only leaf is empty
     w.inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     w.down = (w.inv.x < 0.0f ? 1u : 0u) | (w.inv.y < 0.0f ? 2u : 0u) | (w.inv.z < 0.0f ? 4u : 0u);
 }

@@ -15,6 +15,17 @@ def sample_range(rank, spp_per_rank):
     return rank * spp_per_rank, spp_per_rank
 
 
+def split_samples(rank, world, total_spp):
+    """(first_sample, samples) of `rank` when ONE frame of `total_spp` samples per pixel is divided over `world` ranks
+    (strong scaling).  The remainder goes to the first ranks, one sample each, so no sample is dropped and the ranges are
+    contiguous: rank r starts where rank r-1 ends."""
+    if world <= 0 or not 0 <= rank < world:
+        raise ValueError("rank %d outside a world of %d" % (rank, world))
+    base, extra = divmod(total_spp, world)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
 def tile_owner_mask(width, height, world, rank):
     """Boolean [H, W] mask of the pixels rank `rank` renders under interleaved 32x32 tiles."""
     tiles_x = (width + TILE - 1) // TILE

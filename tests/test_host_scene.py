@@ -240,3 +240,68 @@ def test_synthetic_mesh_bvh_matches_oracle_at_scale():
     assert len(nodes) == nn and np.array_equal(hs.slots()["prim"].astype(np.int32), leaf)
     assert np.array_equal(nodes["bmin"], boxes[:, :3]) and np.array_equal(nodes["bmax"], boxes[:, 3:])
     assert nn > 1000
+
+
+def test_image_decoders_survive_hostile_files_under_asan(tmp_path):
+    """Truncated files, segment lengths too short for their fields, Huffman / quantisation selectors out of range and seeded
+    random byte flips: the JPEG and PNG decoders, built here with AddressSanitizer and UBSan (host code only), must refuse
+    or decode every file without touching memory out of bounds (tests/fuzz_image_decoders.cpp)."""
+    import shutil
+    import subprocess
+
+    from PIL import Image
+
+    if not shutil.which("g++"):
+        pytest.skip("no host compiler")
+    rng = np.random.default_rng(0)
+    Image.fromarray(rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)).save(tmp_path / "sub.jpg", quality=80, subsampling=2)
+    Image.fromarray(rng.integers(0, 256, (24, 40, 3), dtype=np.uint8)).save(tmp_path / "c444.jpg", quality=85, subsampling=0)
+    Image.fromarray(rng.integers(0, 256, (24, 40), dtype=np.uint8)).save(tmp_path / "grey.jpg", quality=90)
+    Image.fromarray(rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)).save(tmp_path / "a.png")
+    exe = str(tmp_path / "fuzz_image_decoders")
+    subprocess.check_call(["g++", "-O2", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "fuzz_image_decoders.cpp"),
+                           os.path.join(ROOT, "rust_raytracer_amd", "csrc", "host", "image_codecs.cpp"), "-lz", "-o", exe])
+    env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=0")
+    r = subprocess.run([exe] + [str(tmp_path / n) for n in ("sub.jpg", "c444.jpg", "grey.jpg", "a.png")], env=env, capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "fuzz ok" in r.stdout
+
+
+def test_scene_description_whose_links_are_no_tree_is_refused():
+    """rrt_scene_create validates a description before it touches the device (so this needs no GPU): a node with two parents,
+    a node no parent names, a child index out of range and a slot range past the end are all refused with a message."""
+    import synth
+
+    hs = synth.host_scene(synth.terrain_desc(12, seed=1))
+    base = hs.desc
+    nodes = hs.nodes()
+    inner = np.nonzero((nodes["b"] & 0x80000000) == 0)[0]
+    assert len(inner) >= 3
+
+    def create_with(mutated):
+        buf = (rrt._Node * len(mutated)).from_buffer_copy(mutated.tobytes())
+        d = rrt._SceneDesc()
+        C.memmove(C.byref(d), C.byref(base), C.sizeof(rrt._SceneDesc))
+        d.nodes = C.cast(buf, C.POINTER(rrt._Node))
+        h = C.c_void_p()
+        rc = rrt.lib().rrt_scene_create(C.byref(d), C.byref(h))
+        return rc, rrt.lib().rrt_last_error().decode()
+
+    # the right child of the root re-used as the right child of the root's left child: two parents (and one node orphaned)
+    m = nodes.copy()
+    left = 1
+    assert (m["b"][left] & 0x80000000) == 0
+    m["a"][left] = m["a"][0]
+    rc, msg = create_with(m)
+    assert rc == 1 and ("two nodes" in msg or "not reachable" in msg), msg
+    m = nodes.copy()
+    m["a"][0] = len(nodes) + 5
+    rc, msg = create_with(m)
+    assert rc == 1 and "out of bounds" in msg
+    m = nodes.copy()
+    leaf = np.nonzero((nodes["b"] & 0x80000000) != 0)[0][-1]
+    m["a"][leaf] = base.n_slots
+    rc, msg = create_with(m)
+    assert rc == 1 and "slot range" in msg
