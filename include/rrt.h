@@ -278,6 +278,17 @@ int rrt_render(rrt_scene*, const rrt_render_params* params, float* rgb_sum, rrt_
  * d_counters: optional device buffer of 2 uint64 {rays, paths} that the kernel adds to. */
 int rrt_render_device(rrt_scene*, const rrt_render_params* params, float* d_rgb_sum, uint64_t* d_counters, void* stream);
 
+/* rrt_render_device for callers that cannot allocate device memory while they render (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit for bit;
+ * the per-sample radiance staging lives in an area of RRT_NOALLOC_STAGING_BYTES that is part of the library's code object (one
+ * copy per GPU, held until the process ends) instead of the scene handle's own buffer, and the call makes no hipMalloc, hipFree,
+ * event creation or other allocating call: kernel launches on `stream` only.  A frame whose samples do not all fit is traced in
+ * several passes.  Limits: width * height * 12 bytes must not exceed RRT_NOALLOC_STAGING_BYTES (11 184 810 pixels), else
+ * RRT_ERR_LIMIT; rrt_scene_set_timing does not cover these renders.  All calls on one GPU share that GPU's area: calls that
+ * overlap in time on one GPU (different streams or scene handles) race; calls on one stream, or ordered by events, do not. */
+#define RRT_NOALLOC_STAGING_BYTES (128u << 20)
+int rrt_render_device_noalloc(rrt_scene*, const rrt_render_params* params, float* d_rgb_sum, uint64_t* d_counters, void* stream);
+
 /* Memory budget of the scene handle's per-sample radiance staging buffer (12 bytes per pixel per sample of a pass;
  * default 16 GiB, 0 restores the default).  A frame whose samples do not fit is traced in several passes; the image
  * does not depend on the split.  No counterpart in the reference (its colours vector, main.rs:115-121, is per pixel). */

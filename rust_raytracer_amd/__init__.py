@@ -129,6 +129,7 @@ def lib():
     L.rrt_intersect_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rrt_render.argtypes = [vp, C.POINTER(_RenderParams), vp, C.POINTER(_Stats)]
     L.rrt_render_device.argtypes = [vp, C.POINTER(_RenderParams), vp, vp, vp]
+    L.rrt_render_device_noalloc.argtypes = [vp, C.POINTER(_RenderParams), vp, vp, vp]
     L.rrt_scene_set_staging_limit.argtypes = [vp, C.c_uint64]
     L.rrt_scene_set_lds_stack.argtypes = [vp, C.c_uint32]
     L.rrt_scene_set_timing.argtypes = [vp, C.c_int]
@@ -327,14 +328,16 @@ class Scene:
     def render_device(self, d_rgb_sum, d_counters=0, stream=0, **kw):
         """Enqueues the render on `stream` into a device buffer (raw pointers as ints); does not synchronise.
         The buffer must hold height x width x 3 floats of the frame that is rendered (the scene's Logistics unless width / height
-        are given); pass out_floats = its size to have that checked here - the library cannot see how large a device buffer is."""
+        are given); pass out_floats = its size to have that checked here - the library cannot see how large a device buffer is.
+        noalloc=True takes rrt_render_device_noalloc: staging in the library's built-in area, no allocation during the call."""
         W, H = kw.get("width") or self.width, kw.get("height") or self.height
         if "out_floats" in kw and kw["out_floats"] < W * H * 3:
             raise ValueError("the output buffer holds %d floats, the %dx%d frame needs %d" % (kw["out_floats"], W, H, W * H * 3))
         p = self._params(kw.get("width"), kw.get("height"), kw.get("samples"), kw.get("first_sample", 0), kw.get("seed", 0),
                          kw.get("background", BG_BLACK), kw.get("max_depth", -1), kw.get("aabb_mode", AABB_TIGHT), kw.get("tile_count", 1),
                          kw.get("tile_index", 0), kw.get("accumulate", False))
-        _check(lib().rrt_render_device(self._h, C.byref(p), d_rgb_sum, d_counters or None, stream or None))
+        entry = lib().rrt_render_device_noalloc if kw.get("noalloc") else lib().rrt_render_device
+        _check(entry(self._h, C.byref(p), d_rgb_sum, d_counters or None, stream or None))
 
     def set_staging_limit(self, nbytes):
         """Memory budget of the per-sample radiance staging buffer (0 = the 16 GiB default)."""

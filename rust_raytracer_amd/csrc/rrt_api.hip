@@ -33,6 +33,13 @@ constexpr size_t kMaxTimedPasses = 4096;   // render passes whose events a scene
 constexpr size_t kSlabCapBytes = 16ull << 30;  // default budget of the per-sample radiance staging buffer (per scene handle, per GPU):
                                                // sized for 288 GB of HBM, so that a 1024x1024 frame at 1024 spp is a single pass
 
+// Staging area of rrt_render_device_noalloc: the per-sample radiance slab of a render pass, held in the code object itself
+// so that the entry point never asks the runtime for memory.  Each GPU the library runs on holds its own copy until the
+// process ends.  In host code the array's NAME is only a handle for hipGetSymbolAddress; kernels, here as everywhere, get the
+// address that call returned for the current device (rrt_scene::static_slab).
+constexpr size_t kStaticSlabBytes = RRT_NOALLOC_STAGING_BYTES;
+static __device__ __align__(256) unsigned char scratch[kStaticSlabBytes];
+
 struct TraceArgs {
     uint32_t W, H;
     uint32_t first_sample;  // stream index of the pass's first sample
@@ -550,6 +557,7 @@ struct rrt_scene {
     DScene d{};
     std::vector<void*> owned;
     float* slab = nullptr;  // per-sample radiance staging, allocated on first render
+    float* static_slab = nullptr;  // this device's copy of `scratch` (rrt_render_device_noalloc), looked up once in rrt_scene_create
     size_t slab_bytes = 0;
     size_t slab_cap = kSlabCapBytes;
     uint32_t res_x = 0, res_y = 0, samples = 0, stack_depth = 1;
@@ -751,6 +759,12 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     std::unique_ptr<rrt_scene, Destroy> owner(new rrt_scene());
     rrt_scene* s = owner.get();
     HIP_TRY(hipGetDevice(&s->device));
+    {
+        // every GPU holds its own copy of the array at its own address: ask for the current device's, once, here
+        void* p = nullptr;
+        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
+        s->static_slab = (float*)p;
+    }
     uint32_t clean_depth = 0;  // clean trees: most stack entries a walk can have pending (sizes the traversal stack)
 #define UP(field, src, count)                                                        \
     do {                                                                             \
@@ -1179,7 +1193,10 @@ static int plan_render(rrt_scene* s, const rrt_render_params* p, RenderPlan* pla
     return RRT_OK;
 }
 
-int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum, uint64_t* d_counters, void* stream) {
+// Enqueues the passes of one render.  static_staging = false: the slab is the scene handle's own buffer, (re)allocated here when
+// the frame needs more; true: the slab is the current device's copy of `scratch` and nothing here allocates, frees or creates
+// anything (no event is recorded either: the per-kernel timing of rrt_scene_set_timing does not cover these renders).
+static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum, uint64_t* d_counters, void* stream, bool static_staging) {
     RenderPlan plan;
     int rc = plan_render(s, p, &plan);
     if (rc) return rc;
@@ -1188,8 +1205,12 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
     if (ta.n_t8 == 0 || plan.spp == 0) return RRT_OK;
     const size_t frame_floats = (size_t)ta.W * ta.H * 3;
     const size_t frame_bytes = frame_floats * sizeof(float);
+    if (static_staging && frame_bytes > kStaticSlabBytes)
+        return rrt_set_error(RRT_ERR_LIMIT, "rrt_render_device_noalloc: a frame of " + std::to_string(ta.W) + " x " + std::to_string(ta.H) + " pixels needs " +
+                                                std::to_string(frame_bytes) + " bytes of staging per sample, the built-in staging area holds " +
+                                                std::to_string(kStaticSlabBytes) + " (at most " + std::to_string(kStaticSlabBytes / 12) + " pixels)");
     // samples per pass: as many as fit the staging buffer, in whole chunks when possible
-    uint64_t per_pass = s->slab_cap / frame_bytes;
+    uint64_t per_pass = (static_staging ? kStaticSlabBytes : s->slab_cap) / frame_bytes;
     if (per_pass == 0) per_pass = 1;
     if (per_pass > plan.spp) per_pass = plan.spp;
     if (per_pass >= kChunk) per_pass -= per_pass % kChunk;
@@ -1198,7 +1219,10 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
     const uint64_t even = ((plan.spp + n_passes - 1) / n_passes + kChunk - 1) / kChunk * kChunk;
     if (even < per_pass) per_pass = even;
     const size_t need_bytes = (size_t)per_pass * frame_bytes;
-    if (s->slab_bytes < need_bytes) {
+    float* const slab = static_staging ? s->static_slab : nullptr;
+    if (static_staging) {
+        if (!slab) return rrt_set_error(RRT_ERR_DEVICE, "rrt_render_device_noalloc: the built-in staging area was not found on this device");
+    } else if (s->slab_bytes < need_bytes) {
         if (s->slab) {
             HIP_TRY(hipDeviceSynchronize());  // earlier renders on any stream may still read the old buffer
             HIP_TRY(hipFree(s->slab));
@@ -1219,7 +1243,7 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
     unsigned long long* cnt = (unsigned long long*)d_counters;
     for (uint32_t done = 0; done < plan.spp; done += (uint32_t)per_pass) {
         hipEvent_t* ev = nullptr;
-        if (s->timing && s->events_used + 3 <= kMaxTimedPasses * 3) {  // passes beyond the cap run untimed until rrt_scene_kernel_times is called
+        if (s->timing && !static_staging && s->events_used + 3 <= kMaxTimedPasses * 3) {  // passes beyond the cap run untimed until rrt_scene_kernel_times is called
             while (s->events.size() < s->events_used + 3) {
                 hipEvent_t e;
                 HIP_TRY(hipEventCreate(&e));
@@ -1244,15 +1268,16 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
         const uint64_t items = (uint64_t)((ta.n_samples + ta.chunk - 1) / ta.chunk) * ta.n_t8;
         if (items > 0x7fffffffull) return rrt_set_error(RRT_ERR_LIMIT, "rrt_render: too many work items in one pass");
         const dim3 grid((unsigned)items);
-#define RRT_LAUNCH(MODE, FEAT) hipLaunchKernelGGL((k_trace<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt)
-#define RRT_LAUNCH_STREAM(MODE, FEAT) hipLaunchKernelGGL((k_trace_stream<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt)
+        float* const pass_slab = static_staging ? slab : s->slab;
+#define RRT_LAUNCH(MODE, FEAT) hipLaunchKernelGGL((k_trace<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt)
+#define RRT_LAUNCH_STREAM(MODE, FEAT) hipLaunchKernelGGL((k_trace_stream<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt)
 #define RRT_PICK(MODE)                                                               \
     do {                                                                             \
         if (s->deep) {                                                               \
             if ((need & ~kPlain) == 0) RRT_LAUNCH_STREAM(MODE, kPlain);              \
             else RRT_LAUNCH_STREAM(MODE, F_ALL);                                     \
         } else if ((need & ~kPlain) == 0) {                                          \
-            if (s->harvest) hipLaunchKernelGGL((k_trace<MODE, kPlain, true>), grid, dim3(kTraceBlock), lds, st, s->d, ta, s->slab, cnt); \
+            if (s->harvest) hipLaunchKernelGGL((k_trace<MODE, kPlain, true>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt); \
             else RRT_LAUNCH(MODE, kPlain);                                           \
         }                                                                            \
         else if ((need & ~kTextured) == 0) RRT_LAUNCH(MODE, kTextured);              \
@@ -1268,12 +1293,23 @@ int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum
 #undef RRT_LAUNCH_STREAM
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev[1], st));
-        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((frame_floats + 255) / 256)), dim3(256), 0, st, s->slab, ta.n_samples, frame_floats, ta.W,
+        hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((frame_floats + 255) / 256)), dim3(256), 0, st, pass_slab, ta.n_samples, frame_floats, ta.W,
                            ta.tiles_x, ta.tile_count, ta.tile_index, (done == 0 && !(p->flags & RRT_RENDER_ACCUMULATE)) ? 1 : 0, d_rgb_sum);
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev[2], st));
     }
     return RRT_OK;
+}
+
+int rrt_render_device(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum, uint64_t* d_counters, void* stream) {
+    return render_passes(s, p, d_rgb_sum, d_counters, stream, false);
+}
+
+// The same render with the slab in the built-in staging area.  Every (sample, pixel) record a pass reads was written by that
+// pass's trace kernel (pixels of other ranks' tiles and beyond the frame's edge are neither written nor read), so nothing in the
+// area has to start at zero and the previous call's contents are simply overwritten.
+int rrt_render_device_noalloc(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum, uint64_t* d_counters, void* stream) {
+    return render_passes(s, p, d_rgb_sum, d_counters, stream, true);
 }
 
 int rrt_render(rrt_scene* s, const rrt_render_params* p, float* rgb_sum, rrt_stats* stats) {
