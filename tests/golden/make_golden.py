@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """Regenerates the committed fixtures under tests/golden/.
 
-* gallery_stats.json — numbers measured on the reference's own gallery render img/cornell_box.png (the only
-  reference-produced output usable as a pin; needs /root/reference, so it is only regenerated where that exists).
+* gallery_stats.json — numbers measured on the reference's own gallery renders img/cornell_box.png, img/globe.png and
+  img/materials.png (the only reference-produced outputs; the last two were made with the sky background that main.rs:259-267
+  keeps commented out).  Needs /root/reference, so it is only regenerated where that exists (`--gallery-only` stops there).
 * rays_<scene>.npz   — fixed ray batches with the oracle's (prim_id, t) answers.
 * render_<scene>.npy — 64x64 oracle renders (radiance sums) at a fixed seed.
 The reference has no tests or golden vectors of its own and cannot be built here (no Rust toolchain), so the
@@ -49,10 +50,35 @@ def gallery_stats():
     }
 
 
+def sky_gallery_stats(name, scene, spp):
+    """Statistics of a gallery render made with the sky background the reference keeps commented out (main.rs:259-267):
+    means, 25-pixel block means (8-bit and linear) and the number of exactly-black pixels."""
+    from PIL import Image
+
+    ref = np.asarray(Image.open("/root/reference/img/%s.png" % name).convert("RGB")).astype(np.float64)
+    assert ref.shape == (500, 500, 3)
+    lin = (ref / 255.99) ** 2
+    B = 25
+    return {
+        "source": "img/%s.png of the reference (500x500, assets/%s at %d spp, sky background of main.rs:259-267)" % (name, scene, spp),
+        "mean_rgb8": ref.reshape(-1, 3).mean(axis=0).tolist(),
+        "mean_linear": lin.reshape(-1, 3).mean(axis=0).tolist(),
+        "black_pixels": int((ref.max(axis=2) == 0).sum()),
+        "block": B,
+        "block_means_rgb8": np.round(ref.reshape(500 // B, B, 500 // B, B, 3).mean(axis=(1, 3)), 4).tolist(),
+        "block_means_linear": np.round(lin.reshape(500 // B, B, 500 // B, B, 3).mean(axis=(1, 3)), 6).tolist(),
+    }
+
+
 def main():
     if os.path.exists("/root/reference/img/cornell_box.png"):
+        stats = gallery_stats()
+        stats["globe"] = sky_gallery_stats("globe", "Globe.json", 1000)
+        stats["materials"] = sky_gallery_stats("materials", "Materials.json", 200)
         with open(os.path.join(HERE, "gallery_stats.json"), "w") as f:
-            json.dump(gallery_stats(), f)
+            json.dump(stats, f)
+    if "--gallery-only" in sys.argv:
+        return
     for name, (bg, spp) in SCENES.items():
         sc = orc.OracleScene.from_file(orc.asset(name + ".json"), {"resolution_x": 64, "resolution_y": 64, "samples": spp})
         ro, rd = raygen.ray_batch(sc, 64, 64, n_random=768, seed=11)

@@ -75,3 +75,44 @@ def test_gallery_cornell_box_statistics():
     assert np.abs(blocks - ref_blocks).max() < 0.02  # worst block straddles the light edge; 0.0026 at 200 spp
     assert np.sqrt(((blocks - ref_blocks) ** 2).mean()) < 0.003
     assert np.allclose(lin[not_light].mean(axis=0), g["mean_linear_not_light"], rtol=0.02)
+
+
+def sky_gallery_check(rgb8, ref, mean_tol=0.1, block_rmse_tol=1e-3, block_max_tol=0.012, black_rel_tol=None):
+    """An 8-bit 500x500 render against the statistics of one of the reference's sky-lit gallery images: mean RGB8 within
+    `mean_tol` code values, 25-pixel block means of the linear image (v/255.99)^2 within `block_rmse_tol` (RMSE) and
+    `block_max_tol` (worst block), count of exactly-black pixels within `black_rel_tol` (relative)."""
+    rgb = rgb8.astype(np.float64)
+    assert rgb.shape == (500, 500, 3)
+    B = ref["block"]
+    assert np.abs(rgb.reshape(-1, 3).mean(axis=0) - np.asarray(ref["mean_rgb8"])).max() < mean_tol
+    lin = (rgb / 255.99) ** 2
+    blocks = lin.reshape(500 // B, B, 500 // B, B, 3).mean(axis=(1, 3))
+    diff = blocks - np.asarray(ref["block_means_linear"])
+    assert np.sqrt((diff ** 2).mean()) < block_rmse_tol
+    assert np.abs(diff).max() < block_max_tol
+    if black_rel_tol is not None:
+        black = int((rgb.max(axis=2) == 0).sum())
+        assert abs(black - ref["black_pixels"]) <= black_rel_tol * ref["black_pixels"], (black, ref["black_pixels"])
+
+
+def test_gallery_globe_statistics():
+    """assets/Globe.json (sphere uv, image texture, bump map) with the sky background of main.rs:259-267 against the reference's
+    img/globe.png (1000 spp): at 64 spp the oracle's mean RGB8 is within 0.006 and the block RMSE 1.7e-4 linear."""
+    with open(os.path.join(GOLD, "gallery_stats.json")) as f:
+        ref = json.load(f)["globe"]
+    spp = 64
+    sc = orc.OracleScene.from_file(orc.asset("Globe.json"))
+    img, _ = sc.render(500, 500, spp, seed=1, bg=orc.BG_SKY)
+    sky_gallery_check(orc.resolve_rgb8(img, spp), ref, mean_tol=0.05, block_rmse_tol=5e-4, block_max_tol=0.006)
+
+
+def test_gallery_materials_statistics():
+    """assets/Materials.json (checker, Lambert, Metal 0.1, Dielectric, the sphere of radius -0.45; importance sampling off) with
+    the sky background against the reference's img/materials.png, at its 200 spp: mean RGB8 within 0.015, block RMSE 5.4e-4
+    linear, 41 362 exactly-black pixels (the black checker squares) against the reference's 41 366."""
+    with open(os.path.join(GOLD, "gallery_stats.json")) as f:
+        ref = json.load(f)["materials"]
+    spp = 200
+    sc = orc.OracleScene.from_file(orc.asset("Materials.json"))
+    img, _ = sc.render(500, 500, spp, seed=1, bg=orc.BG_SKY)
+    sky_gallery_check(orc.resolve_rgb8(img, spp), ref, mean_tol=0.1, block_rmse_tol=1e-3, block_max_tol=0.012, black_rel_tol=0.002)
