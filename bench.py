@@ -1,21 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s on the Cornell box with the glass sphere, 1024x1024 @ 1024 spp per GPU.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config headline|c5] [--shard samples|tiles]
 
-A step is one full render of the frame (1024*1024*1024 camera samples, each traced to termination) with
-the scene already resident in HBM.  With N > 1 (launched by torch.distributed.run, one rank per GPU) every
-rank renders its own 1024-sample range of the per-pixel random streams (first_sample = rank * 1024) and the
-radiance sums are combined with ONE RCCL reduce per step, so N GPUs deliver an N*1024-spp frame: weak scaling.
-`--shard tiles` instead splits one 1024-spp frame into interleaved 32x32 tiles (strong scaling).
+A step is one full render of the frame (1024*1024*1024 camera samples, each traced to termination) with the scene already
+resident in HBM, plus the one collective and the 8-bit resolve.  With N > 1 (launched by torch.distributed.run, one rank per GPU)
+every rank renders its own 1024-sample range of the per-pixel random streams (first_sample = rank * 1024) and the radiance sums
+are combined with ONE RCCL reduce per step, so N GPUs deliver an N*1024-spp frame: weak scaling, and that is `value`.  For N > 1
+the line also carries `strong`: the SAME 1024-spp frame divided over the N GPUs (sample ranges, and interleaved 32x32 tiles),
+timed for the same number of steps after the weak ones.
 
-Rank 0 prints one JSON line.  `roofline` is for the dominant kernel, k_trace: its launch durations are measured
-live with HIP events that the library records around every launch on the render stream, and `achieved` prices the
-rays of one launch with the per-ray byte figure of a queue-based wavefront tracer (192 B per path segment).
-k_trace keeps path state in registers, so its measured HBM traffic (`traffic`, from the committed PMC passes) is the
-12 bytes per path it writes and the kernel is VALU-bound, not HBM-bound.
-`cpu_baseline` times the CPU oracle (a port of the reference's algorithm) on a bounded sample of the same
-frame on this host's cores; it is never part of the product path.
+Rank 0 prints one JSON line.  `roofline` describes the dominant kernel (the path tracer).  Its launch durations are measured live
+with HIP events that the library records around every launch on the render stream.  The kernel keeps all path state on chip, so
+what bounds it is vector-ALU issue, not HBM: `bound` says so, `achieved`/`peak` are vector wave-instructions per second (the
+instruction count per ray and the lane utilisation come from the committed PMC passes of this same command,
+profiles/pmc_counters.json; the duration is live), and `nominal_hbm_*` keep the figure a queue-based wavefront tracer would be
+priced at (192 B per path segment against 8 TB/s), with `traffic` the HBM bytes the kernel really moves per launch.
+`cpu_baseline` times the CPU oracle (a port of the reference's algorithm) on a bounded sample of the same frame on this host's
+cores - all of them (at most 16) and the reference's default of two threads (main.rs:66-72); it is never part of the product path.
 """
 import argparse
 import json
@@ -34,13 +36,22 @@ WIDTH = HEIGHT = 1024
 SPP = 1024
 BYTES_PER_RAY = 192  # wavefront queue traffic per path segment (extend: ray in 32 + hit out 16; shade: 80 in, 64 out)
 HBM_PEAK_GBS = 8000.0
+# Vector-ALU issue: 256 CUs x 4 SIMDs, one wave64 instruction per 2 cycles per SIMD with two or more waves resident, at the
+# 2.4 GHz peak engine clock.
+SIMDS = 1024
+PEAK_CLOCK_GHZ = 2.4
+VALU_PEAK_GINSTR = SIMDS * PEAK_CLOCK_GHZ / 2.0
+# The 10 M-triangle mesh (--config c5): mean node fetches and pair records tested per ray on the clean four-wide tree, counted by
+# the profiling build (tools/perf_mesh.py); bytes per ray by the formula 192 + 32 * nodes + 48 * triangles.
+C5_GRID = 2236
+C5_NODES_PER_RAY = 87.0
+C5_TRIANGLES_PER_RAY = 24.0
 
 
-def cpu_baseline(spp):
+def cpu_baseline(spp, threads):
     """Times the CPU oracle on the full 1024x1024 frame at `spp` samples per pixel (same scene, same RNG, same ray definition)."""
     import orc
 
-    threads = min(len(os.sched_getaffinity(0)), 16)
     sc = orc.OracleScene.from_file(SCENE, {"resolution_x": WIDTH, "resolution_y": HEIGHT, "samples": spp})
     t0 = time.perf_counter()
     _, st = sc.render(WIDTH, HEIGHT, spp, seed=0, threads=threads)
@@ -50,14 +61,24 @@ def cpu_baseline(spp):
             "seconds": dt}
 
 
+def pmc_record(name):
+    path = os.path.join(ROOT, "profiles", "pmc_counters.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f).get(name)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--spp", type=int, default=SPP, help="samples per pixel per GPU per step (the headline config is 1024)")
+    ap.add_argument("--config", choices=["headline", "c5"], default="headline",
+                    help="headline: Cornell box with the glass sphere 1024x1024 @ 1024 spp; c5: the 10 M-triangle mesh at 3840x2160 @ 16 spp per step")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU per step (default: 1024 for the headline config, 16 for c5)")
     ap.add_argument("--shard", choices=["samples", "tiles"], default="samples")
-    ap.add_argument("--cpu-spp", type=int, default=96, help="samples per pixel of the CPU-oracle sample (0 = skip); 96 spp is about 15 s on 16 cores")
+    ap.add_argument("--cpu-spp", type=int, default=96, help="samples per pixel of the CPU-oracle sample (0 = skip); 96 spp is about 20 s on 16 cores")
     ap.add_argument("--aabb", choices=["tight", "reference"], default="tight")
     args = ap.parse_args()
 
@@ -80,74 +101,150 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
 
-    scene = rrt.Scene.load(SCENE, width=WIDTH, height=HEIGHT, samples=args.spp)  # upload happens here, outside the timed region
-    img = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.float32, device=dev)
-    rgb8 = torch.zeros((HEIGHT, WIDTH, 3), dtype=torch.uint8, device=dev)
+    c5 = args.config == "c5"
+    if c5:
+        import synth
+
+        W, H = 3840, 2160
+        spp = args.spp or 16
+        desc = synth.terrain_desc(C5_GRID, seed=1, width=W, height=H, samples=spp)
+        t0 = time.perf_counter()
+        host = synth.host_scene(desc, "BVH_CLEAN")
+        build_s = time.perf_counter() - t0
+        scene = rrt.Scene(host)
+        workload = ("synthetic displaced grid, %d triangles, %dx%d @ %d spp per GPU per step; CLEAN tree (built on the GPU; queries return "
+                    "what the reference's List aggregate returns - not the reference's own BVH, which this mesh makes 250x slower)"
+                    % (2 * C5_GRID * C5_GRID + 2, W, H, spp))
+        bytes_per_ray = BYTES_PER_RAY + 32.0 * C5_NODES_PER_RAY + 48.0 * C5_TRIANGLES_PER_RAY
+    else:
+        W, H = WIDTH, HEIGHT
+        spp = args.spp or SPP
+        host = rrt.HostScene.load(SCENE, width=W, height=H, samples=spp)
+        build_s = sum(host.times())
+        scene = rrt.Scene(host)  # upload happens here, outside the timed region
+        workload = "assets/Cornell_Box_With_Sphere.json %dx%d @ %d spp per GPU per step" % (W, H, spp)
+        bytes_per_ray = float(BYTES_PER_RAY)
+    upload_ms = scene.upload_seconds() * 1e3
+    img = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
+    host_rgb8 = torch.empty((H, W, 3), dtype=torch.uint8).pin_memory()
     counters = torch.zeros(2, dtype=torch.int64, device=dev)
     aabb = rrt.AABB_TIGHT if args.aabb == "tight" else rrt.AABB_REFERENCE
-    if args.shard == "samples":
-        first, count = shard.sample_range(rank, args.spp)
-        kw = dict(samples=count, first_sample=first, seed=0, aabb_mode=aabb)
-    else:
-        kw = dict(samples=args.spp, first_sample=0, seed=0, aabb_mode=aabb, tile_count=world, tile_index=rank)
+    render_stream = torch.cuda.Stream(device=dev)
+    rendered = torch.cuda.Event()
 
-    scene.set_timing(True)
+    def plan(kind, total_spp):
+        """Render arguments of this rank: weak = `total_spp` samples of its own range; strong = its share of ONE `total_spp` frame."""
+        if kind == "weak-samples":
+            first, count = shard.sample_range(rank, total_spp)
+            return dict(samples=count, first_sample=first, seed=0, aabb_mode=aabb), total_spp * world
+        if kind == "strong-samples":
+            first, count = shard.split_samples(rank, world, total_spp)
+            return dict(samples=count, first_sample=first, seed=0, aabb_mode=aabb), total_spp
+        return dict(samples=total_spp, first_sample=0, seed=0, aabb_mode=aabb, tile_count=world, tile_index=rank), total_spp
 
-    def step(ev0=None, ev1=None):
-        stream = torch.cuda.current_stream()
-        if args.shard == "tiles":
-            img.zero_()
-        if ev0 is not None:
-            ev0.record(stream)
-        scene.render_device(img.data_ptr(), counters.data_ptr(), stream.cuda_stream, out_floats=img.numel(), **kw)
-        if ev1 is not None:
-            ev1.record(stream)
+    def step(kw, frame_spp, tiles, ev0=None, ev1=None):
+        with torch.cuda.stream(render_stream):
+            if tiles:
+                img.zero_()
+            if ev0 is not None:
+                ev0.record(render_stream)
+            if kw["samples"] > 0:
+                scene.render_device(img.data_ptr(), counters.data_ptr(), render_stream.cuda_stream, out_floats=img.numel(), **kw)
+            else:
+                img.zero_()  # more ranks than samples: this rank adds nothing
+            if ev1 is not None:
+                ev1.record(render_stream)
+            rendered.record(render_stream)
+        cur = torch.cuda.current_stream()
+        cur.wait_event(rendered)  # the collective below is enqueued behind the render explicitly, not by stream coincidence
         shard.reduce_frame(img, dst=0)  # the one collective of the job (no-op on one GPU)
         if rank == 0:  # time-to-image ends with the 8-bit frame (main.rs:173-186), still in HBM
-            total_spp = args.spp * world if args.shard == "samples" else args.spp
-            rrt.resolve_rgb8_device(img.data_ptr(), WIDTH, HEIGHT, total_spp, rgb8.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            rrt.resolve_rgb8_device(img.data_ptr(), W, H, frame_spp, rgb8.data_ptr(), cur.cuda_stream)
+        render_stream.wait_stream(cur)  # the next step's render must not overwrite the frame under the reduce / resolve
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    counters.zero_()
-    scene.kernel_times()  # forget the warm-up passes
-    torch.cuda.synchronize()
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    fence()
-    t0 = time.perf_counter()
-    for e0, e1 in events:
-        step(e0, e1)
-    fence()
-    elapsed = time.perf_counter() - t0
+    def timed(kind, total_spp, steps, warmup, record_events):
+        kw, frame_spp = plan(kind, total_spp)
+        tiles = kind == "tiles"
+        for _ in range(warmup):
+            step(kw, frame_spp, tiles)
+        fence()
+        counters.zero_()
+        scene.kernel_times()  # forget the warm-up passes
+        torch.cuda.synchronize()
+        events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)] if record_events else [(None, None)] * steps
+        fence()
+        t0 = time.perf_counter()
+        for e0, e1 in events:
+            step(kw, frame_spp, tiles, e0, e1)
+        fence()
+        elapsed = time.perf_counter() - t0
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        c = counters.clone()
+        if world > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        render_ms = [e0.elapsed_time(e1) for e0, e1 in events] if record_events else []
+        return float(t.item()), int(c[0].item()), int(c[1].item()), render_ms, int(counters[0].item())
 
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    c = counters.clone()
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dist.all_reduce(c, op=dist.ReduceOp.SUM)
-    elapsed = float(t.item())
-    rays_total, paths_total = int(c[0].item()), int(c[1].item())
-    render_ms = [e0.elapsed_time(e1) for e0, e1 in events]
+    scene.set_timing(True)
+    main_kind = "weak-samples" if args.shard == "samples" else "tiles"
+    elapsed, rays_total, paths_total, render_ms, rays_rank0 = timed(main_kind, spp, args.steps, args.warmup, True)
     trace_ms, accumulate_ms, passes = scene.kernel_times()
 
+    strong = None
+    if world > 1 and not c5:
+        strong = {}
+        for kind in ("strong-samples", "tiles"):
+            e, r, p, _, _ = timed(kind, spp, args.steps, 1, False)
+            strong[kind.replace("strong-", "")] = {"ms_per_frame": e / max(args.steps, 1) * 1e3, "value": r / e / 1e6, "unit": "Mrays/s",
+                                                   "frame": "%dx%d @ %d spp in total, divided over %d GPUs" % (W, H, spp, world)}
+        scene.kernel_times()
+
+    # the 8-bit frame's way to the host: part of time-to-image, not of `value`
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    host_rgb8.copy_(rgb8, non_blocking=True)
+    torch.cuda.synchronize()
+    d2h_ms = (time.perf_counter() - t0) * 1e3
+
     if rank == 0:
-        launches = max(passes, 1)  # one k_trace launch per pass of the staging buffer
-        rays_per_launch = int(counters[0].item()) / launches
+        launches = max(passes, 1)  # one path-tracer launch per pass of the staging buffer
+        rays_per_launch = rays_rank0 / launches
         k_s = trace_ms / launches * 1e-3
-        achieved = rays_per_launch * BYTES_PER_RAY / k_s / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            with open(pmc) as f:
-                rec = json.load(f)
-            if rec.get("spp") == args.spp and rec.get("width") == WIDTH:
-                traffic = rec.get("hbm_bytes_per_launch")  # PMC passes of the same command, corrected for gfx950
+        nominal = rays_per_launch * bytes_per_ray / k_s / 1e9
+        step_ms = elapsed / max(args.steps, 1) * 1e3
+        pmc = pmc_record("c5" if c5 else "headline")
+        roofline = {"kernel": "k_trace_stream" if c5 else "k_trace", "kernel_ms": k_s * 1e3, "launches_per_step": launches / max(args.steps, 1),
+                    "rays_per_launch": rays_per_launch, "accumulate_ms_per_step": accumulate_ms / max(args.steps, 1),
+                    "render_ms_per_step": float(np.mean(render_ms)) if render_ms else None,
+                    "nominal_hbm_achieved": nominal, "nominal_hbm_frac": nominal / HBM_PEAK_GBS, "bytes_per_ray": bytes_per_ray, "traffic": None}
+        if pmc and pmc.get("spp") == spp and pmc.get("width") == W:
+            roofline["traffic"] = pmc.get("hbm_bytes_per_launch")  # PMC passes of the same command, corrected for gfx950
+            roofline["counters_from"] = pmc.get("source")
+        if c5:
+            roofline.update({"bound": "hbm", "achieved": nominal, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nominal / HBM_PEAK_GBS})
+            if pmc:
+                roofline["hbm_traffic_frac"] = pmc.get("hbm_bytes_per_launch", 0.0) / k_s / 1e9 / HBM_PEAK_GBS
+        else:
+            roofline["bound"] = "valu"
+            roofline["unit"] = "Gwave-instr/s"
+            roofline["peak"] = VALU_PEAK_GINSTR
+            if pmc and pmc.get("valu_wave_instr_per_ray"):
+                per_ray = pmc["valu_wave_instr_per_ray"]
+                achieved = rays_per_launch * per_ray / k_s / 1e9
+                roofline.update({"achieved": achieved, "frac": achieved / VALU_PEAK_GINSTR, "valu_issue_frac": achieved / VALU_PEAK_GINSTR,
+                                 "valu_wave_instr_per_ray": per_ray, "lane_utilisation": pmc.get("lane_utilisation"),
+                                 "salu_instr_per_ray": pmc.get("salu_instr_per_ray"), "valu_busy_frac": pmc.get("valu_busy_frac")})
+            else:
+                roofline.update({"achieved": None, "frac": None})
+            roofline["limiter"] = ("vector ALU issue: SQ_ACTIVE_INST_VALU covers the whole launch; the 192 B/ray figure (nominal_hbm_*) is what a "
+                                   "queue-based tracer would move, this kernel moves about 3.4 B/ray (traffic)")
         out = {
             "metric": "Mrays/sec (whole node) + time-to-image, Cornell box 1024^2 @1024 spp",
             "value": rays_total / elapsed / 1e6,
@@ -155,26 +252,30 @@ def main():
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": elapsed / max(args.steps, 1) * 1e3,
+            "ms_per_step": step_ms,
             "higher_is_better": True,
             "scaling": "weak" if args.shard == "samples" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": "assets/Cornell_Box_With_Sphere.json %dx%d @ %d spp per GPU per step" % (WIDTH, HEIGHT, args.spp),
+            "config": {"workload": workload,
                        "shard": "sample ranges, one RCCL reduce per step" if args.shard == "samples" else "interleaved 32x32 tiles, one RCCL reduce per step",
+                       "value_is": "weak scaling: every GPU traces %d spp of its own, the frame has %d spp" % (spp, spp * world) if args.shard == "samples"
+                                   else "strong scaling: one %d-spp frame divided into interleaved tiles" % spp,
                        "background": "black", "seed": 0, "aabb_mode": args.aabb, "max_depth": 50,
                        "samples_per_second": paths_total / elapsed, "rays_per_path": rays_total / max(paths_total, 1),
-                       "time_to_image_ms": elapsed / max(args.steps, 1) * 1e3},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "kernel": "k_trace", "kernel_ms": k_s * 1e3, "launches_per_step": launches / max(args.steps, 1),
-                         "bytes_per_ray": BYTES_PER_RAY, "rays_per_launch": rays_per_launch,
-                         "accumulate_ms_per_step": accumulate_ms / max(args.steps, 1), "render_ms_per_step": float(np.mean(render_ms)),
-                         "limiter": "vector ALU issue: SQ_ACTIVE_INST_VALU covers the whole launch (profiles/r01_d_summary.md); "
-                                    "the 192 B/ray figure is what a queue-based tracer would move, this kernel moves 3.4 B/ray"},
+                       "time_to_image_ms": upload_ms + step_ms + d2h_ms,
+                       "time_to_image_parts_ms": {"scene_upload": upload_ms, "render_reduce_resolve": step_ms, "rgb8_to_host": d2h_ms,
+                                                  "host_load_and_build_not_included": build_s * 1e3}},
+            "roofline": roofline,
         }
-        if world == 1 and args.cpu_spp > 0:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_spp)
+        if strong is not None:
+            out["strong"] = strong
+        if world == 1 and args.cpu_spp > 0 and not c5:
+            threads = min(len(os.sched_getaffinity(0)), 16)
+            out["cpu_baseline"] = cpu_baseline(args.cpu_spp, threads)
+            two = cpu_baseline(max(args.cpu_spp // 8, 1), 2)  # the reference's default thread count (main.rs:66-72)
+            out["cpu_baseline"]["reference_default_threads"] = {k: two[k] for k in ("value", "unit", "cores", "sample", "seconds")}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

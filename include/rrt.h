@@ -205,10 +205,16 @@ typedef struct rrt_render_params {
  * gives bit for bit what one call over [0,b) gives; without it the call's pixels start from zero. */
 enum { RRT_RENDER_ACCUMULATE = 1 };
 
+/* ≙ the one measurement the reference makes, `Success! Took {} seconds` (main.rs:64, 189-192), split by phase.  All times are
+ * seconds of device time measured with HIP events, for the host-buffer entry points (rrt_render, rrt_render_multi). */
 typedef struct rrt_stats {
-    uint64_t rays;          /* Aggregate::hit calls made by trace (aggregate.rs:24) */
-    uint64_t paths;         /* camera samples traced */
-    double render_seconds;  /* kernel time on the stream (HIP events) for the host-buffer entry points; 0 for _device */
+    uint64_t rays;              /* Aggregate::hit calls made by trace (aggregate.rs:24) */
+    uint64_t paths;             /* camera samples traced */
+    double render_seconds;      /* trace + accumulate kernels; rrt_render_multi: the slowest device */
+    double trace_seconds;       /* the path-tracing kernel alone (same device as render_seconds) */
+    double accumulate_seconds;  /* the per-pixel sums in sample order (main.rs:244-245) */
+    double reduce_seconds;      /* rrt_render_multi: gathering the devices' frames on the first device and adding them; else 0 */
+    double copy_seconds;        /* the frame's way to the device (when it must keep the caller's values) and back to the host */
 } rrt_stats;
 
 /* ---- host side: scene construction -------------------------------------------------------- */
@@ -254,6 +260,10 @@ enum {
 };
 int rrt_host_finalize(rrt_host_scene*, int aggregate);
 const rrt_scene_desc* rrt_host_desc(const rrt_host_scene*); /* valid after finalize/load, owned by the handle */
+/* Host wall-clock seconds of the two phases the reference's total (main.rs:64, 191) contains before tracing: reading and decoding
+ * the scene file with its meshes and images (scene.rs:64-128; 0 for scenes built through rrt_host_add_*), and building the light
+ * list, the aggregate and the flattened arrays (scene.rs:130-159, aggregate.rs:187-322). */
+int rrt_host_scene_times(const rrt_host_scene*, double* load_seconds, double* build_seconds);
 void rrt_host_scene_destroy(rrt_host_scene*);
 
 /* ---- device side ---------------------------------------------------------------------------- */
@@ -261,6 +271,8 @@ void rrt_host_scene_destroy(rrt_host_scene*);
 /* Uploads the flattened scene to the current device's HBM.  ≙ moving Scene into Arc (main.rs:85-95). */
 int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out);
 void rrt_scene_destroy(rrt_scene*);
+/* Host wall-clock seconds rrt_scene_create took (pairing the leaves' triangles, primitive boxes, the copies to HBM). */
+int rrt_scene_upload_seconds(const rrt_scene*, double* seconds);
 
 /* ≙ Aggregate::hit (aggregate.rs:118-124) for n rays: closest hit in (t_min, t_max).
  * o_xyz, d_xyz: n*3 floats.  prim_id[i] = shape index in scene order or -1; t_hit[i] = distance (t_max on miss).
@@ -277,6 +289,24 @@ int rrt_render(rrt_scene*, const rrt_render_params* params, float* rgb_sum, rrt_
 /* Same with a device output buffer; enqueues on `stream` and returns without synchronising.
  * d_counters: optional device buffer of 2 uint64 {rays, paths} that the kernel adds to. */
 int rrt_render_device(rrt_scene*, const rrt_render_params* params, float* d_rgb_sum, uint64_t* d_counters, void* stream);
+
+/* ---- several GPUs of one node in one process ------------------------------------------------------------------
+ * ≙ the thread pool of main.rs:136-165: there N host threads drain one queue of samples into one colour buffer; here one host
+ * thread per GPU traces a share of the frame on a scene replicated in that GPU's HBM, and the shares meet on the first GPU:
+ * every other GPU's frame is copied there over its own xGMI link (the links are point to point, so the N-1 copies run side by
+ * side) and added in device order.  No counterpart of the sharding choice in the reference (its queue is dynamic). */
+enum {
+    RRT_SHARD_SAMPLES = 0, /* device i traces a contiguous range of the samples of every pixel (the first devices take the remainder);
+                              equal to one device's frame up to the f32 rounding of adding N partial sums */
+    RRT_SHARD_TILES = 1    /* device i traces all samples of the 32x32-pixel tiles with index % N == i: bit-identical to one device's frame */
+};
+int rrt_device_count(int* count);
+/* rrt_scene_create on device `device` (the calling thread's current device is left as it was). */
+int rrt_scene_create_on(const rrt_scene_desc* desc, int device, rrt_scene** out);
+/* scenes[0..n): the same description uploaded once per device (two handles on one device are allowed and simply share it).
+ * params->tile_count / tile_index must be 0 (the call does its own sharding).  rgb_sum: host buffer, row-major [y][x][3]; without
+ * RRT_RENDER_ACCUMULATE every pixel is overwritten, with it the samples are added to the sums already there.  stats may be NULL. */
+int rrt_render_multi(rrt_scene* const* scenes, uint32_t n, uint32_t shard_mode, const rrt_render_params* params, float* rgb_sum, rrt_stats* stats);
 
 /* rrt_render_device for callers that cannot allocate device memory while they render (code under HIP graph capture, tight
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit for bit;

@@ -989,16 +989,19 @@ static bool list_hit(const Scene& sc, const std::vector<int>& list, const Ray& r
     }
     return false;
 }
-// aggregate.rs:193-322
-static void new_bvh_helper(const Scene& sc, std::vector<BvhNode>& bvh, std::vector<int> shapes) {
+// aggregate.rs:193-322.  Two things differ from the reference in schedule only, never in result: `boxes[s]` holds
+// Shape::get_bounding_box of shape s, computed once instead of at every use (it is a pure function of the shape), and the two
+// recursive calls of a large node may run on two threads - the right subtree is built into a vector of its own and appended
+// after the left one, which is where the reference's single vector puts it (node links are relative offsets).
+static void new_bvh_helper(const Scene& sc, const std::vector<AABB>& boxes, std::vector<BvhNode>& bvh, std::vector<int> shapes, int threads) {
     AABB total_bounds = aabb_empty();
-    for (int s : shapes) total_bounds = aabb_union(total_bounds, shape_bbox(sc, sc.shapes[s]));
+    for (int s : shapes) total_bounds = aabb_union(total_bounds, boxes[s]);
     if (shapes.size() <= 2) {
         bvh.push_back(BvhNode{true, total_bounds, 0, 0, shapes});
         return;
     }
     AABB centroid_bounds = aabb_empty();
-    for (int s : shapes) centroid_bounds = aabb_union_point(centroid_bounds, aabb_center(shape_bbox(sc, sc.shapes[s])));
+    for (int s : shapes) centroid_bounds = aabb_union_point(centroid_bounds, aabb_center(boxes[s]));
     int cut_axis = aabb_largest_axis(centroid_bounds);
     if (axis_of(centroid_bounds.max, cut_axis) == axis_of(centroid_bounds.min, cut_axis)) {
         bvh.push_back(BvhNode{true, total_bounds, 0, 0, shapes});
@@ -1006,22 +1009,22 @@ static void new_bvh_helper(const Scene& sc, std::vector<BvhNode>& bvh, std::vect
     }
     // slice::sort_by is a stable sort
     std::stable_sort(shapes.begin(), shapes.end(), [&](int a, int b) {
-        float a_c = axis_of(aabb_center(shape_bbox(sc, sc.shapes[a])), cut_axis);
-        float b_c = axis_of(aabb_center(shape_bbox(sc, sc.shapes[b])), cut_axis);
+        float a_c = axis_of(aabb_center(boxes[a]), cut_axis);
+        float b_c = axis_of(aabb_center(boxes[b]), cut_axis);
         return a_c < b_c;
     });
     size_t n = shapes.size();
     std::vector<AABB> reverse_bounds(n, aabb_empty());
     // (0..n-1).rev(): index n-1 is never written and keeps the origin point box
     for (size_t k = n - 1; k-- > 0;) {
-        reverse_bounds[k] = shape_bbox(sc, sc.shapes[shapes[k]]);
+        reverse_bounds[k] = boxes[shapes[k]];
         if (k + 1 < n) reverse_bounds[k] = aabb_union(reverse_bounds[k], reverse_bounds[k + 1]);
     }
     AABB forward_bounds = aabb_empty();
     float min_cost = kTMax;
     size_t min_cost_index = 0;
     for (size_t idx = 0; idx < n - 1; ++idx) {
-        forward_bounds = aabb_union(forward_bounds, shape_bbox(sc, sc.shapes[shapes[idx]]));
+        forward_bounds = aabb_union(forward_bounds, boxes[shapes[idx]]);
         float cost = 1.0f + ((aabb_surface_area(forward_bounds) / aabb_surface_area(total_bounds)) * (float)(idx + 1)) +
                      ((aabb_surface_area(reverse_bounds[idx + 1]) / aabb_surface_area(total_bounds)) * (float)(n - (idx + 1)));
         if (cost < min_cost) {
@@ -1034,10 +1037,21 @@ static void new_bvh_helper(const Scene& sc, std::vector<BvhNode>& bvh, std::vect
         shapes.resize(min_cost_index + 1);
         bvh.push_back(BvhNode{false, aabb_empty(), cut_axis, 0, {}});
         size_t node_idx = bvh.size() - 1;
-        new_bvh_helper(sc, bvh, shapes);
+        std::vector<AABB>().swap(reverse_bounds);
+        if (threads > 1 && n > 32768) {
+            std::vector<BvhNode> right;
+            std::thread other([&]() { new_bvh_helper(sc, boxes, right, std::move(second_half), threads / 2); });
+            new_bvh_helper(sc, boxes, bvh, std::move(shapes), threads - threads / 2);
+            other.join();
+            bvh[node_idx].box = total_bounds;
+            bvh[node_idx].right_offset = bvh.size() - node_idx;
+            bvh.insert(bvh.end(), std::make_move_iterator(right.begin()), std::make_move_iterator(right.end()));
+            return;
+        }
+        new_bvh_helper(sc, boxes, bvh, std::move(shapes), 1);
         bvh[node_idx].box = total_bounds;
         bvh[node_idx].right_offset = bvh.size() - node_idx;
-        new_bvh_helper(sc, bvh, second_half);
+        new_bvh_helper(sc, boxes, bvh, std::move(second_half), 1);
         return;
     }
     bvh.push_back(BvhNode{true, total_bounds, 0, 0, shapes});
@@ -1524,7 +1538,9 @@ int orc_finalize(void* s, int aggregate) {
     if (aggregate == 1) {
         std::vector<int> all(sc->shapes.size());
         for (size_t i = 0; i < all.size(); ++i) all[i] = (int)i;
-        new_bvh_helper(*sc, sc->bvh, all);
+        std::vector<AABB> boxes(sc->shapes.size());
+        for (size_t i = 0; i < boxes.size(); ++i) boxes[i] = shape_bbox(*sc, sc->shapes[i]);
+        new_bvh_helper(*sc, boxes, sc->bvh, std::move(all), (int)std::min(16u, std::max(1u, std::thread::hardware_concurrency())));
     }
     return 0;
 }
@@ -1578,23 +1594,37 @@ void orc_get_shape_bboxes(void* s, float* out6) {
 void orc_intersect_batch(void* s, uint64_t n, const float* o, const float* d, float t_min, float t_max, int aabb_mode, uint32_t seed,
                          int32_t* prim, float* t_hit, uint64_t* stats4) {
     Scene* sc = (Scene*)s;
-    Workspace ws = get_workspace(*sc);
-    Stats st;
-    for (uint64_t i = 0; i < n; ++i) {
-        Ray r{v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2])};
-        Rng g = rng_seed(seed, (uint32_t)i, 0);
-        HitCtx cx{&g, 0, &st};
-        int shape;
-        float t;
-        st.rays++;
-        if (aggregate_hit(*sc, ws, r, t_min, t_max, aabb_mode, cx, &shape, &t)) {
-            prim[i] = shape;
-            t_hit[i] = t;
-        } else {
-            prim[i] = -1;
-            t_hit[i] = t_max;
+    // rays are independent (each has its own keyed stream): large jobs are cut into contiguous runs, one per thread
+    // (a walk through the reference's tree with the reference's box test visits a large part of a big tree)
+    const uint64_t work = n * (sc->aggregate == 0 ? (uint64_t)sc->shapes.size() : std::max<uint64_t>(64u, sc->bvh.size() / 8u));
+    const unsigned threads = work < (1u << 22) ? 1u : std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+    std::vector<Stats> stats(threads);
+    auto run = [&](unsigned tid) {
+        Workspace ws = get_workspace(*sc);
+        Stats& st = stats[tid];
+        const uint64_t lo = n * tid / threads, hi = n * (tid + 1) / threads;
+        for (uint64_t i = lo; i < hi; ++i) {
+            Ray r{v3(o[3 * i], o[3 * i + 1], o[3 * i + 2]), v3(d[3 * i], d[3 * i + 1], d[3 * i + 2])};
+            Rng g = rng_seed(seed, (uint32_t)i, 0);
+            HitCtx cx{&g, 0, &st};
+            int shape;
+            float t;
+            st.rays++;
+            if (aggregate_hit(*sc, ws, r, t_min, t_max, aabb_mode, cx, &shape, &t)) {
+                prim[i] = shape;
+                t_hit[i] = t;
+            } else {
+                prim[i] = -1;
+                t_hit[i] = t_max;
+            }
         }
-    }
+    };
+    std::vector<std::thread> pool;
+    for (unsigned tid = 1; tid < threads; ++tid) pool.emplace_back(run, tid);
+    run(0);
+    for (auto& th : pool) th.join();
+    Stats st;
+    for (const Stats& x : stats) { st.rays += x.rays; st.nodes += x.nodes; st.tri_tests += x.tri_tests; st.sphere_tests += x.sphere_tests; }
     if (stats4) { stats4[0] = st.rays; stats4[1] = st.nodes; stats4[2] = st.tri_tests; stats4[3] = st.sphere_tests; }
 }
 

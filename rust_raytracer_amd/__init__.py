@@ -17,6 +17,7 @@ LIB_PATH = os.environ.get("RRT_LIB") or os.path.join(_HERE, "librrt_hip.so")
 BG_BLACK, BG_SKY = 0, 1
 AABB_TIGHT, AABB_REFERENCE = 0, 1
 RENDER_ACCUMULATE = 1
+SHARD_SAMPLES, SHARD_TILES = 0, 1
 KIND_TRIANGLE, KIND_SPHERE, KIND_MEDIUM = 0, 1, 2
 T_MIN = 0.001
 T_MAX = float(np.finfo(np.float32).max)
@@ -87,7 +88,13 @@ class _RenderParams(C.Structure):
 
 
 class _Stats(C.Structure):
-    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("render_seconds", C.c_double)]
+    _fields_ = [("rays", C.c_uint64), ("paths", C.c_uint64), ("render_seconds", C.c_double), ("trace_seconds", C.c_double),
+                ("accumulate_seconds", C.c_double), ("reduce_seconds", C.c_double), ("copy_seconds", C.c_double)]
+
+
+def _stats_dict(st):
+    return {"rays": st.rays, "paths": st.paths, "seconds": st.render_seconds, "trace_seconds": st.trace_seconds,
+            "accumulate_seconds": st.accumulate_seconds, "reduce_seconds": st.reduce_seconds, "copy_seconds": st.copy_seconds}
 
 
 _lib = None
@@ -122,9 +129,14 @@ def lib():
     L.rrt_host_finalize.argtypes = [vp, C.c_int]
     L.rrt_host_desc.argtypes = [vp]
     L.rrt_host_desc.restype = C.POINTER(_SceneDesc)
+    L.rrt_host_scene_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.rrt_host_scene_destroy.argtypes = [vp]
     L.rrt_scene_create.argtypes = [C.POINTER(_SceneDesc), C.POINTER(vp)]
     L.rrt_scene_destroy.argtypes = [vp]
+    L.rrt_scene_create_on.argtypes = [C.POINTER(_SceneDesc), C.c_int, C.POINTER(vp)]
+    L.rrt_scene_upload_seconds.argtypes = [vp, C.POINTER(C.c_double)]
+    L.rrt_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.rrt_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32, C.POINTER(_RenderParams), vp, C.POINTER(_Stats)]
     L.rrt_intersect_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
     L.rrt_intersect_batch_device.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp, vp]
     L.rrt_render.argtypes = [vp, C.POINTER(_RenderParams), vp, C.POINTER(_Stats)]
@@ -269,6 +281,12 @@ class HostScene:
         return np.array(list(c.origin) + list(c.lower_left_corner) + list(c.horizontal) + list(c.vertical) + list(c.u) + list(c.v)
                         + [c.lens_radius], dtype=np.float32)
 
+    def times(self):
+        """(load_seconds, build_seconds): reading + decoding the scene file, and building lights / aggregate / flattened arrays."""
+        a, b = C.c_double(0), C.c_double(0)
+        _check(lib().rrt_host_scene_times(self._h, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def close(self):
         if self._h:
             lib().rrt_host_scene_destroy(self._h)
@@ -284,13 +302,23 @@ class HostScene:
 class Scene:
     """A scene resident in the current GPU's HBM."""
 
-    def __init__(self, host):
+    def __init__(self, host, device=None):
+        """Uploads to the current device, or to `device` (an index) when given."""
         self.host = host
         d = host.desc
         self.width, self.height, self.samples = d.resolution_x, d.resolution_y, d.samples
         h = C.c_void_p()
-        _check(lib().rrt_scene_create(C.byref(d), C.byref(h)))
+        if device is None:
+            _check(lib().rrt_scene_create(C.byref(d), C.byref(h)))
+        else:
+            _check(lib().rrt_scene_create_on(C.byref(d), device, C.byref(h)))
         self._h = h
+
+    def upload_seconds(self):
+        """Host wall-clock seconds rrt_scene_create took."""
+        t = C.c_double(0)
+        _check(lib().rrt_scene_upload_seconds(self._h, C.byref(t)))
+        return t.value
 
     @classmethod
     def load(cls, path, width=0, height=0, samples=0, aspect_ratio=float("nan"), tree="BVH"):
@@ -323,7 +351,7 @@ class Scene:
         p = self._params(width, height, samples, first_sample, seed, background, max_depth, aabb_mode, tile_count, tile_index, accumulate)
         st = _Stats()
         _check(lib().rrt_render(self._h, C.byref(p), img.ctypes.data, C.byref(st)))
-        return img, {"rays": st.rays, "paths": st.paths, "seconds": st.render_seconds}
+        return img, _stats_dict(st)
 
     def render_device(self, d_rgb_sum, d_counters=0, stream=0, **kw):
         """Enqueues the render on `stream` into a device buffer (raw pointers as ints); does not synchronise.
@@ -374,6 +402,29 @@ class Scene:
             self.close()
         except Exception:
             pass
+
+
+def device_count():
+    n = C.c_int(0)
+    _check(lib().rrt_device_count(C.byref(n)))
+    return n.value
+
+
+def render_multi(scenes, shard=SHARD_SAMPLES, width=None, height=None, samples=None, first_sample=0, seed=0, background=BG_BLACK, max_depth=-1,
+                 aabb_mode=AABB_TIGHT, out=None, accumulate=False):
+    """rrt_render_multi: one frame traced by several Scene handles (one per GPU, the same description in each), one host thread
+    per handle, the shares gathered and added on the first handle's device.  Returns (float32 [H, W, 3] sums, stats dict)."""
+    first = scenes[0]
+    W, H = width or first.width, height or first.height
+    img = out if out is not None else np.zeros((H, W, 3), dtype=np.float32)
+    if img.shape != (H, W, 3) or img.dtype != np.float32 or not img.flags["C_CONTIGUOUS"]:
+        raise ValueError("out must be a C-contiguous float32 array of shape (H, W, 3)")
+    p = _RenderParams(width or 0, height or 0, samples or 0, first_sample, seed, background, max_depth, aabb_mode, 0, 0,
+                      RENDER_ACCUMULATE if accumulate else 0)
+    handles = (C.c_void_p * len(scenes))(*[s._h for s in scenes])
+    st = _Stats()
+    _check(lib().rrt_render_multi(handles, len(scenes), shard, C.byref(p), img.ctypes.data, C.byref(st)))
+    return img, _stats_dict(st)
 
 
 def write_png(path, rgb8, create_new=True):

@@ -8,7 +8,9 @@
 // -t is accepted and validated like the reference's (a positive integer, default 2) but selects nothing here: the
 // samples are traced by the GPU, not by host threads.
 // Extensions (not in the reference): --background black|sky (main.rs:259-270 keeps the sky gradient commented out),
-// --seed N, --aabb tight|reference, --samples N / --width N / --height N overriding the scene's Logistics.
+// --seed N, --aabb tight|reference, --samples N / --width N / --height N overriding the scene's Logistics,
+// --gpus N (the reference's N host threads draining one sample queue, main.rs:136-165, become N GPUs each tracing a share of the
+// frame: rrt_render_multi) with --shard samples|tiles, and --stats (the reference's single "Took N seconds" split by phase).
 #include <fcntl.h>
 #include <unistd.h>
 
@@ -67,7 +69,10 @@ struct Progress {
                  "        --aabb <tight|reference>         Bounding-box test of the BVH walk (default tight)\n"
                  "        --tree <host|gpu|clean>          Where and how a \"BVH\" aggregate is built: the reference's tree on the host\n"
                  "                                         (default) or on the GPU, or the clean tree with the List aggregate's results\n"
-                 "        --samples <N> --width <N> --height <N>   Override the scene's Logistics\n\nARGS:\n"
+                 "        --samples <N> --width <N> --height <N>   Override the scene's Logistics\n"
+                 "        --gpus <N>                       GPUs of this node that share the frame (default 1)\n"
+                 "        --shard <samples|tiles>          How they share it: sample ranges (default) or interleaved 32x32 tiles\n"
+                 "        --stats                          Print the seconds spent per phase\n\nARGS:\n"
                  "    <IN_SCENE_FILE>    The scene specification to render\n"
                  "    <OUT_FILEPATH>     The relative filepath to write the output image to\n",
                  why);
@@ -89,6 +94,8 @@ int main(int argc, char** argv) {
     const char* thread_count = "2";
     uint32_t seed = 0, bg = RRT_BG_BLACK, aabb = RRT_AABB_TIGHT, o_samples = 0, o_width = 0, o_height = 0;
     int tree = RRT_AGGREGATE_BVH;
+    uint32_t gpus = 1, shard = RRT_SHARD_SAMPLES;
+    bool print_stats = false;
     std::vector<const char*> positional;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
@@ -118,7 +125,15 @@ int main(int argc, char** argv) {
             else if (v == "gpu") tree = RRT_AGGREGATE_BVH_GPU;
             else if (v == "clean") tree = RRT_AGGREGATE_BVH_CLEAN;
             else usage("--tree takes host, gpu or clean");
-        } else if (a == "-h" || a == "--help") usage("help requested");
+        } else if (a == "--gpus") {
+            if (!parse_u32(value("--gpus"), &gpus) || gpus == 0) usage("--gpus requires a positive integer");
+        } else if (a == "--shard") {
+            std::string v = value("--shard");
+            if (v == "samples") shard = RRT_SHARD_SAMPLES;
+            else if (v == "tiles") shard = RRT_SHARD_TILES;
+            else usage("--shard takes samples or tiles");
+        } else if (a == "--stats") print_stats = true;
+        else if (a == "-h" || a == "--help") usage("help requested");
         else if (a.size() > 1 && a[0] == '-') usage(("Found argument '" + a + "' which wasn't expected, or isn't valid in this context").c_str());
         else positional.push_back(argv[i]);
     }
@@ -146,8 +161,20 @@ int main(int argc, char** argv) {
         die(msg);
     };
 
-    rrt_scene* scene = nullptr;
-    if (rrt_scene_create(desc, &scene) != RRT_OK) fail(std::string("Failed to upload the scene: ") + rrt_last_error());
+    // the scene is replicated: one upload per GPU (it is small next to 288 GB of HBM)
+    int visible = 0;
+    if (rrt_device_count(&visible) != RRT_OK) fail(std::string("Failed to count the GPUs: ") + rrt_last_error());
+    if ((int)gpus > visible) fail("--gpus " + std::to_string(gpus) + " but only " + std::to_string(visible) + " GPU(s) are visible");
+    std::vector<rrt_scene*> scenes(gpus, nullptr);
+    double upload_seconds = 0.0;
+    for (uint32_t i = 0; i < gpus; ++i) {
+        if (rrt_scene_create_on(desc, (int)i, &scenes[i]) != RRT_OK) fail(std::string("Failed to upload the scene: ") + rrt_last_error());
+        double t = 0.0;
+        rrt_scene_upload_seconds(scenes[i], &t);
+        upload_seconds += t;
+    }
+    rrt_stats total;
+    std::memset(&total, 0, sizeof total);
 
     std::vector<float> sums((size_t)W * H * 3, 0.0f);
     Progress progress((uint64_t)W * H * spp, 20);  // main.rs:130-134
@@ -166,20 +193,42 @@ int main(int argc, char** argv) {
         p.max_depth = -1;
         p.aabb_mode = aabb;
         p.flags = done ? RRT_RENDER_ACCUMULATE : 0;
-        if (rrt_render(scene, &p, sums.data(), nullptr) != RRT_OK) fail(std::string("Tracing failed: ") + rrt_last_error());
+        rrt_stats st;
+        if (rrt_render_multi(scenes.data(), gpus, shard, &p, sums.data(), &st) != RRT_OK) fail(std::string("Tracing failed: ") + rrt_last_error());
+        total.rays += st.rays;
+        total.paths += st.paths;
+        total.render_seconds += st.render_seconds;
+        total.trace_seconds += st.trace_seconds;
+        total.accumulate_seconds += st.accumulate_seconds;
+        total.reduce_seconds += st.reduce_seconds;
+        total.copy_seconds += st.copy_seconds;
         progress.update((uint64_t)W * H * p.samples);
     }
     progress.done();  // main.rs:166-169
 
     std::vector<uint8_t> rgb((size_t)W * H * 3);  // main.rs:171-186
+    const auto resolve_start = std::chrono::steady_clock::now();
     if (rrt_resolve_rgb8(sums.data(), W, H, spp, rgb.data()) != RRT_OK) fail(std::string("Failed to finalize the image: ") + rrt_last_error());
+    const auto png_start = std::chrono::steady_clock::now();
     if (rrt_write_png(positional[1], rgb.data(), W, H, 0) != RRT_OK) {  // main.rs:187-197
         std::fprintf(stderr, "Failed to encode the png for output: %s\n", rrt_last_error());
         unlink(positional[1]);
         return 1;
     }
-    std::printf("Success! Took %g seconds\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - program_start).count());
-    rrt_scene_destroy(scene);
+    const auto finished = std::chrono::steady_clock::now();
+    std::printf("Success! Took %g seconds\n", std::chrono::duration<double>(finished - program_start).count());
+    if (print_stats) {
+        double load_seconds = 0.0, build_seconds = 0.0;
+        rrt_host_scene_times(host, &load_seconds, &build_seconds);
+        std::printf("  load %.6f s | bvh + flatten %.6f s | upload %.6f s (%u GPU%s) | render %.6f s (trace %.6f, accumulate %.6f) | "
+                    "reduce %.6f s | frame copies %.6f s | resolve %.6f s | png %.6f s\n",
+                    load_seconds, build_seconds, upload_seconds, gpus, gpus == 1 ? "" : "s", total.render_seconds, total.trace_seconds,
+                    total.accumulate_seconds, total.reduce_seconds, total.copy_seconds,
+                    std::chrono::duration<double>(png_start - resolve_start).count(), std::chrono::duration<double>(finished - png_start).count());
+        std::printf("  %llu rays, %llu paths, %.1f Mrays/s over the render phase\n", (unsigned long long)total.rays, (unsigned long long)total.paths,
+                    total.render_seconds > 0.0 ? (double)total.rays / total.render_seconds * 1e-6 : 0.0);
+    }
+    for (rrt_scene* sc : scenes) rrt_scene_destroy(sc);
     rrt_host_scene_destroy(host);
     return 0;
 }

@@ -3,6 +3,7 @@
 #include "../rrt_bvh_build.hpp"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -304,6 +305,12 @@ void fill_tri_slot(const HostShape& s, uint32_t prim, rrt_slot* slot, rrt_tri_sh
 }  // namespace
 
 std::string SceneBuild::finalize(int aggregate) {
+    const auto started = std::chrono::steady_clock::now();
+    struct Stopwatch {  // build_seconds on every way out
+        SceneBuild* b;
+        std::chrono::steady_clock::time_point t0;
+        ~Stopwatch() { b->build_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+    } stopwatch{this, started};
     if (materials.size() > 0x00ffffffu) return "too many materials";
     const bool bvh = aggregate != RRT_AGGREGATE_LIST;
     BuildCtx cx;
@@ -493,6 +500,12 @@ int rrt_host_finalize(rrt_host_scene* s, int aggregate) {
         std::string e = s->b.finalize(aggregate);
         return e.empty() ? RRT_OK : fail_scene(e);
     });
+}
+int rrt_host_scene_times(const rrt_host_scene* s, double* load_seconds, double* build_seconds) {
+    RRT_NEED(s);
+    if (load_seconds) *load_seconds = s->b.load_seconds;
+    if (build_seconds) *build_seconds = s->b.build_seconds;
+    return RRT_OK;
 }
 const rrt_scene_desc* rrt_host_desc(const rrt_host_scene* s) {
     if (!s || !s->b.finalized) {

@@ -35,6 +35,7 @@ struct SceneBuild {
     uint32_t res_x = 0, res_y = 0, samples = 0;
     bool use_importance = true;
     bool finalized = false;
+    double load_seconds = 0.0, build_seconds = 0.0;  // host wall clock: reading + decoding the scene file; finalize()
 
     // flattened
     std::vector<rrt_node> nodes;

@@ -1,6 +1,7 @@
 // Scene file loading: the JSON scene format of the reference (scene.rs:64-619), .obj meshes as the
 // wavefront_obj 7.0.0 crate presents them to scene.rs:501-561 (per-object 0-based indices, polygons
 // as triangle fans), and image textures through decode_image_file.
+#include <chrono>
 #include <cctype>
 #include <cmath>
 #include <cstdio>
@@ -453,6 +454,7 @@ struct Loader {
 }  // namespace
 
 std::string load_scene_file(const std::string& path, uint32_t ow, uint32_t oh, uint32_t os, float oaspect, int tree, SceneBuild* out) {
+    const auto started = std::chrono::steady_clock::now();
     bool ok;
     std::string text = read_file(path, &ok);
     if (!ok) return "Failed to read scene spec file.";
@@ -497,6 +499,7 @@ std::string load_scene_file(const std::string& path, uint32_t ow, uint32_t oh, u
         if (agg.kind != Json::String) bail("'Aggregate' is not a string.");
         if (agg.str != "List" && agg.str != "BVH") bail("Unknown Aggregate 'type' " + agg.str + " given.");
         // `tree` says where and how a "BVH" is built; a "List" stays a list
+        out->load_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
         std::string e = out->finalize(agg.str == "BVH" ? tree : RRT_AGGREGATE_LIST);
         if (!e.empty()) bail(e);
     } catch (const LoadError& e) {

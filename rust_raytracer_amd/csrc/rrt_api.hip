@@ -2,12 +2,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rrt_device.hpp"
@@ -568,6 +570,7 @@ struct rrt_scene {
     bool harvest = false;   // single leaf, 1..kHarvestLights lights, each one a primitive of the leaf: light densities come out of the closest-hit query
     uint32_t n_spheres = 0, n_media = 0, n_btris = 0, n_materials = 0, n_textures = 0;
     int device = 0;
+    double upload_seconds = 0.0;  // host wall clock of rrt_scene_create
     // optional per-kernel timing: three events per pass (before k_trace, between the kernels, after k_accumulate)
     bool timing = false;
     std::vector<hipEvent_t> events;  // pool
@@ -751,6 +754,7 @@ static std::vector<float> tight_boxes(const rrt_scene_desc* d) {
 
 static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     if (!desc || !out) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_create: NULL argument");
+    const auto started = std::chrono::steady_clock::now();
     uint32_t tree_depth = 1;
     int rc = validate_desc(desc, &tree_depth);
     if (rc) return rc;
@@ -1038,12 +1042,36 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         if (desc->materials[i].bump >= 0) s->features |= F_BUMP | F_TEX;
         if (desc->materials[i].type == RRT_MAT_ISOTROPIC) s->features |= F_MEDIUM;
     }
+    s->upload_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
     *out = owner.release();
     return RRT_OK;
 }
 
 int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     return rrt_guard("rrt_scene_create", [&]() -> int { return scene_create(desc, out); });
+}
+
+int rrt_scene_create_on(const rrt_scene_desc* desc, int device, rrt_scene** out) {
+    int before = -1, count = 0;
+    HIP_TRY(hipGetDeviceCount(&count));
+    if (device < 0 || device >= count) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_create_on: no device " + std::to_string(device) + " (" + std::to_string(count) + " visible)");
+    HIP_TRY(hipGetDevice(&before));
+    HIP_TRY(hipSetDevice(device));
+    const int rc = rrt_scene_create(desc, out);
+    (void)hipSetDevice(before);
+    return rc;
+}
+
+int rrt_device_count(int* count) {
+    if (!count) return rrt_set_error(RRT_ERR_INVALID, "rrt_device_count: NULL argument");
+    HIP_TRY(hipGetDeviceCount(count));
+    return RRT_OK;
+}
+
+int rrt_scene_upload_seconds(const rrt_scene* s, double* seconds) {
+    if (!s || !seconds) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_upload_seconds: NULL argument");
+    *seconds = s->upload_seconds;
+    return RRT_OK;
 }
 
 int rrt_scene_set_staging_limit(rrt_scene* s, uint64_t bytes) {
@@ -1312,6 +1340,23 @@ int rrt_render_device_noalloc(rrt_scene* s, const rrt_render_params* p, float* d
     return render_passes(s, p, d_rgb_sum, d_counters, stream, true);
 }
 
+// Sums the (trace, accumulate) durations of the passes recorded since `mark` and forgets them again unless the caller's own
+// timing is on (then they stay for rrt_scene_kernel_times).  The stream must have been synchronised.
+static int passes_since(rrt_scene* s, size_t mark, bool keep, double* trace_s, double* accumulate_s) {
+    double t = 0.0, a = 0.0;
+    for (size_t i = mark; i + 3 <= s->events_used; i += 3) {
+        float ms = 0.0f;
+        HIP_TRY(hipEventElapsedTime(&ms, s->events[i], s->events[i + 1]));
+        t += ms;
+        HIP_TRY(hipEventElapsedTime(&ms, s->events[i + 1], s->events[i + 2]));
+        a += ms;
+    }
+    if (!keep) s->events_used = mark;
+    *trace_s = t * 1e-3;
+    *accumulate_s = a * 1e-3;
+    return RRT_OK;
+}
+
 int rrt_render(rrt_scene* s, const rrt_render_params* p, float* rgb_sum, rrt_stats* stats) {
     RenderPlan plan;
     int rc = plan_render(s, p, &plan);
@@ -1320,37 +1365,287 @@ int rrt_render(rrt_scene* s, const rrt_render_params* p, float* rgb_sum, rrt_sta
     size_t bytes = (size_t)plan.ta.W * plan.ta.H * 3 * sizeof(float);
     float* d_img = nullptr;
     uint64_t* d_cnt = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};  // before the copy in, before the render, after it, after the copy out
+    const bool user_timing = s->timing;
+    const size_t mark = s->events_used;
     auto cleanup = [&]() {
         (void)hipFree(d_img);
         (void)hipFree(d_cnt);
-        if (e0) (void)hipEventDestroy(e0);
-        if (e1) (void)hipEventDestroy(e1);
+        for (hipEvent_t e : ev)
+            if (e) (void)hipEventDestroy(e);
+        s->timing = user_timing;
     };
     TRY2(hipMalloc((void**)&d_img, bytes));
     TRY2(hipMalloc((void**)&d_cnt, 16));
-    // pixels of tiles this call does not own keep the caller's values
-    TRY2(hipMemcpy(d_img, rgb_sum, bytes, hipMemcpyHostToDevice));
-    TRY2(hipMemset(d_cnt, 0, 16));
-    TRY2(hipEventCreate(&e0));
-    TRY2(hipEventCreate(&e1));
-    TRY2(hipEventRecord(e0, nullptr));
+    for (hipEvent_t& e : ev) TRY2(hipEventCreate(&e));
+    TRY2(hipEventRecord(ev[0], nullptr));
+    // pixels of tiles this call does not own, and sums a call with RRT_RENDER_ACCUMULATE adds to, are the caller's values
+    const bool keeps_values = (p->flags & RRT_RENDER_ACCUMULATE) != 0 || plan.ta.tile_count > 1;
+    if (keeps_values) TRY2(hipMemcpyAsync(d_img, rgb_sum, bytes, hipMemcpyHostToDevice, nullptr));
+    TRY2(hipMemsetAsync(d_cnt, 0, 16, nullptr));
+    TRY2(hipEventRecord(ev[1], nullptr));
+    s->timing = stats != nullptr || user_timing;
     rc = rrt_render_device(s, p, d_img, d_cnt, nullptr);
     if (rc) { cleanup(); return rc; }
-    TRY2(hipEventRecord(e1, nullptr));
-    TRY2(hipEventSynchronize(e1));
-    TRY2(hipMemcpy(rgb_sum, d_img, bytes, hipMemcpyDeviceToHost));
+    TRY2(hipEventRecord(ev[2], nullptr));
+    TRY2(hipMemcpyAsync(rgb_sum, d_img, bytes, hipMemcpyDeviceToHost, nullptr));
+    TRY2(hipEventRecord(ev[3], nullptr));
+    TRY2(hipEventSynchronize(ev[3]));
     if (stats) {
         uint64_t c[2];
         TRY2(hipMemcpy(c, d_cnt, 16, hipMemcpyDeviceToHost));
-        float ms = 0.0f;
-        TRY2(hipEventElapsedTime(&ms, e0, e1));
+        float ms_in = 0.0f, ms = 0.0f, ms_out = 0.0f;
+        TRY2(hipEventElapsedTime(&ms_in, ev[0], ev[1]));
+        TRY2(hipEventElapsedTime(&ms, ev[1], ev[2]));
+        TRY2(hipEventElapsedTime(&ms_out, ev[2], ev[3]));
+        std::memset(stats, 0, sizeof *stats);
         stats->rays = c[0];
         stats->paths = c[1];
         stats->render_seconds = (double)ms * 1e-3;
+        stats->copy_seconds = ((double)ms_in + (double)ms_out) * 1e-3;
+        rc = passes_since(s, mark, user_timing, &stats->trace_seconds, &stats->accumulate_seconds);
+        if (rc) { cleanup(); return rc; }
     }
     cleanup();
     return RRT_OK;
+}
+
+// ---- several GPUs in one process ------------------------------------------------------------------------------------------
+// ≙ main.rs:136-165 (N worker threads, one colour buffer).  One host thread per scene handle: it makes the handle's device
+// current, traces that device's share into a frame in that device's HBM and records an event.  The first device then gathers:
+// frame i is copied into a landing buffer on device 0 (hipMemcpyPeerAsync, each peer over its own xGMI link, on a stream of
+// its own so the copies overlap) and, in device order, added to device 0's frame (sample ranges) or its owner's tiles are
+// taken over (tiles), one float per thread.
+namespace {
+struct MultiWorker {
+    rrt_scene* scene = nullptr;
+    rrt_render_params params{};
+    float* d_img = nullptr;       // on scene->device
+    uint64_t* d_cnt = nullptr;    // on scene->device
+    float* d_landing = nullptr;   // on the first device (workers 1..n-1)
+    hipStream_t stream = nullptr;       // on scene->device
+    hipStream_t copy_stream = nullptr;  // on the first device
+    hipEvent_t begin = nullptr, end = nullptr, landed = nullptr;
+    size_t mark = 0;
+    bool user_timing = false;
+    int rc = RRT_OK;
+    std::string error;
+    uint64_t counters[2] = {0, 0};
+    double render_s = 0.0, trace_s = 0.0, accumulate_s = 0.0;
+};
+}  // namespace
+
+__global__ void k_add_frame(float* __restrict__ into, const float* __restrict__ from, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) into[i] = into[i] + from[i];
+}
+
+// Tile sharding: the pixels of the tiles device `tile_index` owns are taken over as they are (no arithmetic: the frame stays
+// bit-identical to a single device's).
+__global__ void k_take_tiles(float* __restrict__ into, const float* __restrict__ from, size_t n, uint32_t W, uint32_t tiles_x, uint32_t tile_count,
+                             uint32_t tile_index) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t pixel = i / 3;
+    const uint32_t x = (uint32_t)(pixel % W), y = (uint32_t)(pixel / W);
+    if (((y >> 5) * tiles_x + (x >> 5)) % tile_count == tile_index) into[i] = from[i];
+}
+
+static int render_multi(rrt_scene* const* scenes, uint32_t n, uint32_t shard_mode, const rrt_render_params* p, float* rgb_sum, rrt_stats* stats) {
+    if (!scenes || n == 0 || !p || !rgb_sum) return rrt_set_error(RRT_ERR_INVALID, "rrt_render_multi: NULL argument");
+    if (n > 64) return rrt_set_error(RRT_ERR_INVALID, "rrt_render_multi: more than 64 scene handles");
+    if (shard_mode > RRT_SHARD_TILES) return rrt_set_error(RRT_ERR_INVALID, "rrt_render_multi: unknown shard_mode");
+    if (p->tile_count > 1 || p->tile_index != 0) return rrt_set_error(RRT_ERR_INVALID, "rrt_render_multi: tile_count / tile_index must be 0 (the call shards the frame itself)");
+    for (uint32_t i = 0; i < n; ++i)
+        if (!scenes[i]) return rrt_set_error(RRT_ERR_INVALID, "rrt_render_multi: NULL scene handle");
+    for (uint32_t i = 0; i < n; ++i)
+        for (uint32_t j = 0; j < i; ++j)
+            if (scenes[i] == scenes[j]) return rrt_set_error(RRT_ERR_INVALID, "rrt_render_multi: a scene handle appears twice (one render at a time per handle)");
+    const uint32_t W = p->width ? p->width : scenes[0]->res_x, H = p->height ? p->height : scenes[0]->res_y;
+    const uint32_t spp = p->samples ? p->samples : scenes[0]->samples;
+    if (W == 0 || H == 0) return rrt_set_error(RRT_ERR_INVALID, "rrt_render_multi: zero resolution");
+    const size_t frame_floats = (size_t)W * H * 3, bytes = frame_floats * sizeof(float);
+    const bool accumulate = (p->flags & RRT_RENDER_ACCUMULATE) != 0;
+    int caller_device = -1;
+    HIP_TRY(hipGetDevice(&caller_device));
+    const int first_device = scenes[0]->device;
+
+    std::vector<MultiWorker> w(n);
+    // shares: contiguous sample ranges (the remainder goes to the first devices, one sample each) or interleaved tiles
+    const uint32_t base = spp / n, extra = spp % n;
+    uint32_t next_sample = p->first_sample;
+    for (uint32_t i = 0; i < n; ++i) {
+        w[i].scene = scenes[i];
+        w[i].params = *p;
+        w[i].params.width = W;
+        w[i].params.height = H;
+        // sample ranges: the caller's sums go into the first device's share only (the others' shares are added to it);
+        // tiles: every device continues the sums of its own pixels
+        w[i].params.flags = (accumulate && (i == 0 || shard_mode == RRT_SHARD_TILES)) ? RRT_RENDER_ACCUMULATE : 0u;
+        if (shard_mode == RRT_SHARD_SAMPLES) {
+            const uint32_t mine = base + (i < extra ? 1u : 0u);
+            w[i].params.samples = mine;
+            w[i].params.first_sample = next_sample;
+            next_sample += mine;
+        } else {
+            w[i].params.samples = spp;
+            w[i].params.tile_count = n;
+            w[i].params.tile_index = i;
+        }
+    }
+    auto release = [&]() {
+        for (MultiWorker& k : w) {
+            (void)hipSetDevice(k.scene->device);
+            if (k.stream) (void)hipStreamSynchronize(k.stream);
+            (void)hipFree(k.d_img);
+            (void)hipFree(k.d_cnt);
+            if (k.begin) (void)hipEventDestroy(k.begin);
+            if (k.end) (void)hipEventDestroy(k.end);
+            if (k.stream) (void)hipStreamDestroy(k.stream);
+            k.scene->timing = k.user_timing;
+            (void)hipSetDevice(first_device);
+            if (k.copy_stream) (void)hipStreamSynchronize(k.copy_stream);
+            (void)hipFree(k.d_landing);
+            if (k.landed) (void)hipEventDestroy(k.landed);
+            if (k.copy_stream) (void)hipStreamDestroy(k.copy_stream);
+        }
+        (void)hipSetDevice(caller_device);
+    };
+#define MULTI_TRY(expr)                                                                                                      \
+    do {                                                                                                                     \
+        hipError_t e_ = (expr);                                                                                              \
+        if (e_ != hipSuccess) { release(); return rrt_set_error(RRT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+    for (MultiWorker& k : w) k.user_timing = k.scene->timing;
+    // buffers: each device's frame and counters; on the first device one landing buffer per other frame
+    for (uint32_t i = 0; i < n; ++i) {
+        MultiWorker& k = w[i];
+        MULTI_TRY(hipSetDevice(k.scene->device));
+        MULTI_TRY(hipMalloc((void**)&k.d_img, bytes));
+        MULTI_TRY(hipMalloc((void**)&k.d_cnt, 16));
+        MULTI_TRY(hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking));
+        MULTI_TRY(hipEventCreate(&k.begin));
+        MULTI_TRY(hipEventCreate(&k.end));
+        if (i > 0) {
+            MULTI_TRY(hipSetDevice(first_device));
+            MULTI_TRY(hipMalloc((void**)&k.d_landing, bytes));
+            MULTI_TRY(hipStreamCreateWithFlags(&k.copy_stream, hipStreamNonBlocking));
+            MULTI_TRY(hipEventCreate(&k.landed));
+        }
+    }
+    hipEvent_t copy_in[2] = {nullptr, nullptr}, reduce_ev[2] = {nullptr, nullptr}, copy_out[2] = {nullptr, nullptr};
+    auto release_all = [&]() {
+        (void)hipSetDevice(first_device);
+        for (hipEvent_t e : {copy_in[0], copy_in[1], reduce_ev[0], reduce_ev[1], copy_out[0], copy_out[1]})
+            if (e) (void)hipEventDestroy(e);
+        release();
+    };
+#undef MULTI_TRY
+#define MULTI_TRY(expr)                                                                                                      \
+    do {                                                                                                                     \
+        hipError_t e_ = (expr);                                                                                              \
+        if (e_ != hipSuccess) { release_all(); return rrt_set_error(RRT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
+    } while (0)
+    MULTI_TRY(hipSetDevice(first_device));
+    for (hipEvent_t* e : {&copy_in[0], &copy_in[1], &reduce_ev[0], &reduce_ev[1], &copy_out[0], &copy_out[1]}) MULTI_TRY(hipEventCreate(e));
+    // with ACCUMULATE the first device's frame starts from the caller's sums (tiles: every device's frame does, see the workers)
+    MULTI_TRY(hipEventRecord(copy_in[0], w[0].stream));
+    if (accumulate) MULTI_TRY(hipMemcpyAsync(w[0].d_img, rgb_sum, bytes, hipMemcpyHostToDevice, w[0].stream));
+    MULTI_TRY(hipEventRecord(copy_in[1], w[0].stream));
+
+    // one host thread per handle (main.rs:138-147)
+    auto work = [&](uint32_t i) {
+        MultiWorker& k = w[i];
+        auto fail = [&](hipError_t e, const char* what) {
+            k.rc = RRT_ERR_DEVICE;
+            k.error = std::string(what) + ": " + hipGetErrorString(e);
+        };
+        hipError_t e = hipSetDevice(k.scene->device);
+        if (e != hipSuccess) return fail(e, "hipSetDevice");
+        if ((e = hipMemsetAsync(k.d_cnt, 0, 16, k.stream)) != hipSuccess) return fail(e, "hipMemsetAsync");
+        if (i > 0 && shard_mode == RRT_SHARD_TILES && accumulate &&
+            (e = hipMemcpyAsync(k.d_img, rgb_sum, bytes, hipMemcpyHostToDevice, k.stream)) != hipSuccess)
+            return fail(e, "hipMemcpyAsync");
+        if ((e = hipEventRecord(k.begin, k.stream)) != hipSuccess) return fail(e, "hipEventRecord");
+        k.mark = k.scene->events_used;
+        k.scene->timing = true;
+        if (k.params.samples != 0) {
+            k.rc = render_passes(k.scene, &k.params, k.d_img, k.d_cnt, k.stream, false);
+            if (k.rc) {
+                k.error = rrt_last_error();
+                return;
+            }
+        } else if (!(accumulate && (i == 0 || shard_mode == RRT_SHARD_TILES))) {
+            if ((e = hipMemsetAsync(k.d_img, 0, bytes, k.stream)) != hipSuccess) return fail(e, "hipMemsetAsync");  // nothing to trace: a frame of zeros
+        }
+        if ((e = hipEventRecord(k.end, k.stream)) != hipSuccess) return fail(e, "hipEventRecord");
+        if ((e = hipEventSynchronize(k.end)) != hipSuccess) return fail(e, "hipEventSynchronize");
+        float ms = 0.0f;
+        if ((e = hipEventElapsedTime(&ms, k.begin, k.end)) != hipSuccess) return fail(e, "hipEventElapsedTime");
+        k.render_s = (double)ms * 1e-3;
+        k.rc = passes_since(k.scene, k.mark, k.user_timing, &k.trace_s, &k.accumulate_s);
+        if (k.rc) k.error = rrt_last_error();
+        if ((e = hipMemcpy(k.counters, k.d_cnt, 16, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "hipMemcpy");
+    };
+    {
+        std::vector<std::thread> pool;
+        for (uint32_t i = 1; i < n; ++i) pool.emplace_back(work, i);
+        work(0);
+        for (std::thread& t : pool) t.join();
+    }
+    for (const MultiWorker& k : w)
+        if (k.rc) {
+            const int rc = k.rc;
+            const std::string msg = "rrt_render_multi, device " + std::to_string(k.scene->device) + ": " + k.error;
+            release_all();
+            return rrt_set_error(rc, msg);
+        }
+    // gather on the first device: the copies run side by side (one stream, one link each), the adds in device order
+    MULTI_TRY(hipSetDevice(first_device));
+    MULTI_TRY(hipEventRecord(reduce_ev[0], w[0].stream));
+    for (uint32_t i = 1; i < n; ++i) {
+        MULTI_TRY(hipStreamWaitEvent(w[i].copy_stream, reduce_ev[0], 0));
+        MULTI_TRY(hipMemcpyPeerAsync(w[i].d_landing, first_device, w[i].d_img, w[i].scene->device, bytes, w[i].copy_stream));
+        MULTI_TRY(hipEventRecord(w[i].landed, w[i].copy_stream));
+    }
+    for (uint32_t i = 1; i < n; ++i) {
+        MULTI_TRY(hipStreamWaitEvent(w[0].stream, w[i].landed, 0));
+        const dim3 grid((unsigned)((frame_floats + 255) / 256));
+        if (shard_mode == RRT_SHARD_TILES)
+            hipLaunchKernelGGL(k_take_tiles, grid, dim3(256), 0, w[0].stream, w[0].d_img, w[i].d_landing, frame_floats, W, (W + 31) / 32, n, i);
+        else hipLaunchKernelGGL(k_add_frame, grid, dim3(256), 0, w[0].stream, w[0].d_img, w[i].d_landing, frame_floats);
+        MULTI_TRY(hipGetLastError());
+    }
+    MULTI_TRY(hipEventRecord(reduce_ev[1], w[0].stream));
+    MULTI_TRY(hipEventRecord(copy_out[0], w[0].stream));
+    MULTI_TRY(hipMemcpyAsync(rgb_sum, w[0].d_img, bytes, hipMemcpyDeviceToHost, w[0].stream));
+    MULTI_TRY(hipEventRecord(copy_out[1], w[0].stream));
+    MULTI_TRY(hipEventSynchronize(copy_out[1]));
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        for (const MultiWorker& k : w) {
+            stats->rays += k.counters[0];
+            stats->paths += k.counters[1];
+            if (k.render_s >= stats->render_seconds) {
+                stats->render_seconds = k.render_s;
+                stats->trace_seconds = k.trace_s;
+                stats->accumulate_seconds = k.accumulate_s;
+            }
+        }
+        float ms_in = 0.0f, ms_red = 0.0f, ms_out = 0.0f;
+        MULTI_TRY(hipEventElapsedTime(&ms_in, copy_in[0], copy_in[1]));
+        MULTI_TRY(hipEventElapsedTime(&ms_red, reduce_ev[0], reduce_ev[1]));
+        MULTI_TRY(hipEventElapsedTime(&ms_out, copy_out[0], copy_out[1]));
+        stats->reduce_seconds = (double)ms_red * 1e-3;
+        stats->copy_seconds = ((double)ms_in + (double)ms_out) * 1e-3;
+    }
+#undef MULTI_TRY
+    release_all();
+    return RRT_OK;
+}
+
+int rrt_render_multi(rrt_scene* const* scenes, uint32_t n, uint32_t shard_mode, const rrt_render_params* p, float* rgb_sum, rrt_stats* stats) {
+    return rrt_guard("rrt_render_multi", [&]() -> int { return render_multi(scenes, n, shard_mode, p, rgb_sum, stats); });
 }
 
 int rrt_resolve_rgb8_device(const float* d_sum, uint32_t W, uint32_t H, uint32_t spp, uint8_t* d_out, void* stream) {

@@ -3,7 +3,7 @@ axis-parallel rays (zero direction components), and rays aimed at primitive vert
 import numpy as np
 
 
-def ray_batch(oracle_scene, W, H, n_random=4096, seed=0):
+def ray_batch(oracle_scene, W, H, n_random=4096, seed=0, max_corners=4000):
     rng = np.random.default_rng(seed)
     bb = oracle_scene.shape_bboxes()
     lo = bb[:, :3].min(axis=0)
@@ -45,6 +45,8 @@ def ray_batch(oracle_scene, W, H, n_random=4096, seed=0):
     dirs.append(d)
     # 5. rays aimed exactly at box corners / centres of every primitive (vertex- and edge-grazing)
     corners = []
+    if len(bb) > 100000:  # huge meshes: aim at a sample of the primitives
+        bb = bb[rng.choice(len(bb), max_corners, replace=False)]
     for b in bb:
         for cx in (b[0], b[3]):
             for cy in (b[1], b[4]):
@@ -52,8 +54,8 @@ def ray_batch(oracle_scene, W, H, n_random=4096, seed=0):
                     corners.append([cx, cy, cz])
         corners.append(0.5 * (b[:3] + b[3:]))
     corners = np.asarray(corners, dtype=np.float32)
-    if len(corners) > 4000:
-        corners = corners[rng.choice(len(corners), 4000, replace=False)]
+    if len(corners) > max_corners:
+        corners = corners[rng.choice(len(corners), max_corners, replace=False)]
     o = np.repeat(c[None, :], len(corners), axis=0).astype(np.float32)
     d = (corners - o).astype(np.float32)
     origins.append(o)

@@ -94,3 +94,24 @@ def test_accumulate_flag_continues_the_sample_sums_bit_exactly(gpu):
     assert part.tobytes() == whole.tobytes()
     fresh, _ = sc.render(samples=5, first_sample=4, seed=11, out=part.copy())  # without the flag the call starts from zero
     assert fresh.tobytes() != whole.tobytes()
+
+
+@pytest.mark.gpu
+def test_cli_gpus_and_stats(gpu, tmp_path):
+    """--gpus N shares the frame between GPUs (rrt_render_multi); --stats prints the phases the reference's one number
+    (main.rs:64, 191) lumps together.  With tiles the picture is the single-GPU picture whatever N is."""
+    import rust_raytracer_amd as rrt
+    from PIL import Image
+
+    scene = os.path.join(ASSETS, "Cornell_Box.json")
+    n = min(rrt.device_count(), 2)
+    out = tmp_path / "a.png"
+    r = run("--width", "64", "--height", "64", "--samples", "130", "--seed", "5", "--gpus", str(n), "--shard", "tiles", "--stats", scene, str(out))
+    assert r.returncode == 0, r.stderr
+    for word in ("load ", "bvh + flatten ", "upload ", "render ", "reduce ", "resolve ", "png ", "Mrays/s"):
+        assert word in r.stdout, word
+    sc = rrt.Scene.load(scene, width=64, height=64, samples=130)
+    sums, _ = sc.render(seed=5)
+    assert (np.asarray(Image.open(out).convert("RGB")) == rrt.resolve_rgb8(sums, 130)).all()
+    r = run("--gpus", "99", scene, str(tmp_path / "b.png"))
+    assert r.returncode != 0 and "GPU(s) are visible" in r.stderr and not (tmp_path / "b.png").exists()

@@ -305,3 +305,37 @@ def test_scene_description_whose_links_are_no_tree_is_refused():
     m["a"][leaf] = base.n_slots
     rc, msg = create_with(m)
     assert rc == 1 and "slot range" in msg
+
+
+def test_rust_bindings_agree_with_the_header_and_the_python_bindings():
+    """rrt-sys/src/lib.rs cannot be compiled here (no Rust toolchain), so it is read as text: every function the header declares
+    must be declared there with the same number of parameters, and every struct's size and field offsets written there must be the
+    ones ctypes computes for the Python mirror of the same struct (the C side holds the same numbers in static_asserts)."""
+    header = open(os.path.join(ROOT, "include", "rrt.h")).read()
+    rust = open(os.path.join(ROOT, "rrt-sys", "src", "lib.rs")).read()
+    header_nc = re.sub(r"/\*.*?\*/", "", header, flags=re.S)
+    decl = {m.group(1): m.group(2) for m in re.finditer(r"\b(rrt_[a-z0-9_]+)\s*\(([^;{]*?)\)\s*;", header_nc)}
+    assert len(decl) >= 30
+    rust_nc = re.sub(r"//[^\n]*", "", rust)
+    rdecl = {m.group(1): m.group(2) for m in re.finditer(r"pub fn (rrt_[a-z0-9_]+)\s*\(([^)]*)\)", rust_nc)}
+    for name, args in decl.items():
+        assert name in rdecl, "rrt-sys does not declare %s" % name
+        n_c = 0 if args.strip() in ("", "void") else args.count(",") + 1
+        n_r = 0 if not rdecl[name].strip() else rdecl[name].count(":")
+        assert n_c == n_r, "%s: %d parameters in rrt.h, %d in rrt-sys" % (name, n_c, n_r)
+    mirrors = {"rrt_node": rrt._Node, "rrt_slot": rrt._Slot, "rrt_tri_shade": rrt._TriShade, "rrt_sphere": rrt._Sphere, "rrt_medium": rrt._Medium,
+               "rrt_material": rrt._Material, "rrt_texture": rrt._Texture, "rrt_light": rrt._Light, "rrt_camera": rrt._Camera,
+               "rrt_scene_desc": rrt._SceneDesc, "rrt_render_params": rrt._RenderParams, "rrt_stats": rrt._Stats}
+    for name, cls in mirrors.items():
+        body = re.search(r"pub struct %s \{(.*?)\n\}" % name, rust, flags=re.S).group(1)
+        fields = re.findall(r"pub (\w+):[^,]*,\s*// offset (\d+)", body)
+        assert [f.rstrip("_") for f, _ in fields] == [f[0] for f in cls._fields_], name
+        for (fname, off), cf in zip(fields, cls._fields_):
+            assert int(off) == getattr(cls, cf[0]).offset, "%s.%s" % (name, fname)
+        size = int(re.search(r"size_of::<%s>\(\) == (\d+)" % name, rust).group(1))
+        assert size == C.sizeof(cls), name
+    layout = open(os.path.join(ROOT, "rust_raytracer_amd", "csrc", "rrt_abi_layout.cpp")).read()
+    for name, cls in mirrors.items():
+        assert "RRT_SIZE(%s, %d)" % (name, C.sizeof(cls)) in layout
+        for cf in cls._fields_:
+            assert "RRT_AT(%s, %s, %d)" % (name, cf[0], getattr(cls, cf[0]).offset) in layout, (name, cf[0])
