@@ -330,6 +330,11 @@ int rrt_scene_set_staging_limit(rrt_scene*, uint64_t bytes);
  * Vec on the host heap, aggregate.rs:352). */
 int rrt_scene_set_lds_stack(rrt_scene*, uint32_t entries);
 
+/* Shallow trees (the asset scenes) with constant textures are traced on a pooled schedule - a wave keeps 160 paths in LDS and
+ * runs one kind of work at a time over 64 of them - unless this is switched off (enable = 0: one path per lane, all kinds of work
+ * in every turn).  Changes speed only, never results.  No counterpart in the reference. */
+int rrt_scene_set_pooling(rrt_scene*, int enable);
+
 /* Per-kernel timing (≙ the reference's only instrumentation, the wall clock of main.rs:64, 191, split by kernel).
  * While enabled, every render pass records device events around its trace and accumulate kernels on the caller's
  * stream; rrt_scene_kernel_times waits for the recorded passes, returns the summed durations in milliseconds and the

@@ -287,6 +287,7 @@ extern "C" {
                             stats: *mut rrt_stats) -> c_int;
     pub fn rrt_scene_set_staging_limit(s: *mut rrt_scene, bytes: u64) -> c_int;
     pub fn rrt_scene_set_lds_stack(s: *mut rrt_scene, entries: u32) -> c_int;
+    pub fn rrt_scene_set_pooling(s: *mut rrt_scene, enable: c_int) -> c_int;
     pub fn rrt_scene_set_timing(s: *mut rrt_scene, enable: c_int) -> c_int;
     pub fn rrt_scene_kernel_times(s: *mut rrt_scene, trace_ms: *mut f64, accumulate_ms: *mut f64, passes: *mut u32) -> c_int;
     /// ≙ main.rs:173-186

@@ -144,6 +144,7 @@ def lib():
     L.rrt_render_device_noalloc.argtypes = [vp, C.POINTER(_RenderParams), vp, vp, vp]
     L.rrt_scene_set_staging_limit.argtypes = [vp, C.c_uint64]
     L.rrt_scene_set_lds_stack.argtypes = [vp, C.c_uint32]
+    L.rrt_scene_set_pooling.argtypes = [vp, C.c_int]
     L.rrt_scene_set_timing.argtypes = [vp, C.c_int]
     L.rrt_scene_kernel_times.argtypes = [vp, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_uint32)]
     L.rrt_resolve_rgb8.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, vp]
@@ -374,6 +375,10 @@ class Scene:
     def set_lds_stack(self, entries):
         """Deep trees: stack entries per ray kept in LDS by the render kernel (0 = the default); speed only, same results."""
         _check(lib().rrt_scene_set_lds_stack(self._h, entries))
+
+    def set_pooling(self, enable=True):
+        """Shallow plain scenes: the pooled schedule (default) or one path per lane; speed only, same results."""
+        _check(lib().rrt_scene_set_pooling(self._h, 1 if enable else 0))
 
     def set_timing(self, enable=True):
         """Record device events around the trace and accumulate kernels of every following render pass."""

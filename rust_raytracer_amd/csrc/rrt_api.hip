@@ -52,6 +52,7 @@ struct TraceArgs {
     uint32_t stack_depth;                                // LDS stack entries per lane (the cooperative-leaf area follows the stack)
     uint32_t chunk;                                      // samples of each pixel handled by one wave item (divides kChunk)
     uint32_t coop_lanes, shade_lanes;                    // k_trace_stream: paused / finished lanes that trigger a leaf / shading phase
+    uint32_t n_items;                                    // k_trace_pool: (tile, chunk) items of the pass, handed out through an atomic counter
 };
 
 // ---- the trace kernel for shallow trees (at most kDeepTreeNodes nodes; deep trees: k_trace_stream) ------------------------
@@ -117,13 +118,6 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
             valid = px < ta.W && py < ta.H;
             if (valid) {
                 g = rng_seed(ta.seed, py * ta.W + px, ta.first_sample + smp);
-                if (RRT_DUP & 32) {
-                    uint32_t p2 = py * ta.W + px;
-                    RRT_OPAQUE(p2);
-                    Rng g2 = rng_seed(ta.seed, p2, ta.first_sample + smp);
-                    Ray r2 = camera_ray(sc.cam, px, py, ta.W, ta.H, g2);
-                    RRT_KEEP(r2.d.x); RRT_KEEP(r2.d.y); RRT_KEEP(r2.d.z); RRT_KEEP(r2.o.x);
-                }
                 r = camera_ray(sc.cam, px, py, ta.W, ta.H, g);
                 thr = mk3(1.0f, 1.0f, 1.0f);
                 depth = 0;
@@ -139,13 +133,6 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
             unsigned char* area = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
             float harvest[kHarvestLights];
             hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
-            if (RRT_DUP & 1) {
-                Ray r2 = r;
-                RRT_OPAQUE(r2.o.x);
-                float harvest2[kHarvestLights];
-                Hit h2 = closest_hit_sift<AABB_MODE, FEAT, HARVEST>(sc, valid, r2, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest2);
-                RRT_KEEP(h2.t); RRT_KEEP(h2.slot); RRT_KEEP(h2.det);
-            }
             RRT_TICK(1)
             if (valid) {
                 ++rays;
@@ -186,6 +173,293 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
 #ifdef RRT_PHASE_PROFILE
     if (counters && lane == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&counters[2 + i], pc[i]);
+#endif
+    if (counters) {
+        for (int off = 32; off > 0; off >>= 1) {
+            rays += __shfl_down(rays, off);
+            paths += __shfl_down(paths, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[0], rays);
+            atomicAdd(&counters[1], paths);
+        }
+    }
+}
+
+
+// ---- the trace kernel for shallow trees, pooled ---------------------------------------------------------------------------
+// Same paths, same arithmetic, same results as k_trace; what differs is who runs when.  In k_trace each lane owns one path
+// and the wave steps query - shade - query in lockstep, so every branch of the shading code (light hit, glass, Lambert towards a
+// triangle light, Lambert cosine lobe, fresh camera ray ...) runs in every turn of the loop for the handful of lanes that need it:
+// 0.455 of the lanes of an average vector instruction do useful work.  Here a wave keeps a POOL of kPool paths in LDS (16 dwords
+// each), every path tagged with what it waits for, and each turn of the loop picks ONE kind of work that has 64 paths waiting,
+// pulls those 64 into registers, runs that one piece of code at full width and files the paths under what they wait for next:
+//   FREE   a slot without a path            -> draw a sample, make the camera ray                     -> TRACE
+//   TRACE  has a ray                        -> closest hit (sifting query), finish the last bounce's density, look up the
+//                                              material, for Lambert make the light-or-lobe draws    -> END / GEN / LTRI / LCS
+//   END    missed, hit a light, depth limit -> radiance, store the sample                             -> FREE
+//   GEN    glass, metal, phase function     -> shade                                                  -> TRACE
+//   LTRI   Lambert, towards a triangle light-> shade                                                  -> TRACE
+//   LCS    Lambert, cosine lobe or sphere light (one sincos / basis block, see sample_scatter_direction) -> TRACE
+// The draws of a path are made in the reference's order whatever the schedule (the light-or-lobe draws are the first of their
+// bounce either way), every sample still goes to slab[sample][y][x], and k_accumulate adds in sample order: bit-identical frames.
+// Waves are persistent: the grid fills the chip once and a wave that has drawn all samples of its (tile, chunk) item takes the
+// next item from an atomic counter, so a launch has no ramp of short-lived blocks and its tail is one item long.
+#ifdef RRT_PHASE_PROFILE
+__device__ unsigned long long g_pool_prof[24];  // profiling build only: per kind of work, steps | paths served | cycles
+#endif
+#ifndef RRT_POOL
+#define RRT_POOL 128
+#endif
+#ifndef RRT_POOL_WAVES
+#define RRT_POOL_WAVES 4
+#endif
+constexpr uint32_t kPool = RRT_POOL;    // paths per wave: 16 x 128 x 4 B = 8 KB; with the query's work area 10 KB: four waves per SIMD
+constexpr uint32_t kPoolSiftCap = 128;  // candidate list of the sifting query (a wave iteration lists about 120, flushed in two parts)
+constexpr uint32_t kPoolWaves = RRT_POOL_WAVES;  // waves per SIMD the LDS request leaves room for
+enum : uint32_t { P_OX, P_OY, P_OZ, P_DX, P_DY, P_DZ, P_TX, P_TY, P_TZ, P_G0, P_G1, P_PIX, P_META, P_PDF_K, P_T, P_HIT, kPoolFields };
+enum : uint32_t { C_FREE = 0, C_TRACE = 1, C_END = 2, C_GEN = 3, C_LTRI = 4, C_LCS = 5, kClasses = 6 };
+// P_META: bits 0..2 class, 3 a diffuse bounce's density is pending, 4 the light-or-lobe draw chose a light, 5..12 depth, 13..31 sample
+constexpr uint32_t kPoolMaxDepth = 255, kPoolMaxSamples = 1u << 19;
+constexpr size_t kPoolBytesPerWave = sift_bytes(kPoolSiftCap) + kHarvestBytesPerWave + (size_t)kPoolFields * kPool * 4;
+
+template <int AABB_MODE, uint32_t FEAT, bool HARVEST>
+__global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters,
+                                                                        uint32_t* __restrict__ item_counter) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t lane = threadIdx.x;
+    uint32_t* stack = lds_stack + lane;
+    unsigned char* area = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
+    uint32_t* pool = (uint32_t*)(area + sift_bytes(kPoolSiftCap) + kHarvestBytesPerWave);
+    uint32_t* list = (uint32_t*)(area + 64 * 8);  // the step's slot list lives where the query will keep its candidate list: read before that
+#define POOL(f, slot) pool[(f) * kPool + (slot)]
+    for (uint32_t s = lane; s < kPool; s += 64u) POOL(P_META, s) = C_FREE;
+    __threadfence_block();
+    uint32_t cnt[kClasses] = {kPool, 0u, 0u, 0u, 0u, 0u};  // wave-uniform
+    uint32_t x0 = 0, y0 = 0, s0 = 0, item_size = 0, next = 0;  // the item samples are drawn from, and the next undrawn one
+    bool exhausted = false;                                    // no items left in the frame
+    unsigned long long rays = 0, paths = 0;
+    const size_t frame_pixels = (size_t)ta.W * ta.H;
+#ifdef RRT_PHASE_PROFILE
+    unsigned long long prof_steps[kClasses] = {0, 0, 0, 0, 0, 0}, prof_lanes[kClasses] = {0, 0, 0, 0, 0, 0}, prof_cycles[kClasses] = {0, 0, 0, 0, 0, 0};
+    unsigned long long prof_tick = __builtin_readcyclecounter();
+    uint32_t prof_phase = kClasses;
+#define RRT_POOL_PROFILE_STEP()                                                         \
+    {                                                                                   \
+        const unsigned long long now_ = __builtin_readcyclecounter();                   \
+        _Pragma("unroll") for (uint32_t c_ = 0; c_ < kClasses; ++c_) if (prof_phase == c_) prof_cycles[c_] += now_ - prof_tick; \
+        prof_tick = now_;                                                               \
+    }
+#else
+#define RRT_POOL_PROFILE_STEP()
+#endif
+    for (;;) {
+        RRT_POOL_PROFILE_STEP()
+        // ---- which kind of work: a kind with a full wave of paths waiting (ending paths first: they free slots), else fresh
+        // samples while slots are free, else the fullest kind
+        uint32_t phase = kClasses;
+        const bool can_draw = !exhausted && cnt[C_FREE] != 0u;
+        if (cnt[C_END] >= 64u) phase = C_END;
+        else if (cnt[C_LCS] >= 64u) phase = C_LCS;
+        else if (cnt[C_LTRI] >= 64u) phase = C_LTRI;
+        else if (cnt[C_GEN] >= 64u) phase = C_GEN;
+        else if (can_draw && cnt[C_FREE] >= 64u) phase = C_FREE;
+        else if (cnt[C_TRACE] >= 64u) phase = C_TRACE;
+        else {
+            uint32_t most = can_draw ? cnt[C_FREE] : 0u;
+            if (most != 0u) phase = C_FREE;
+#pragma unroll
+            for (uint32_t c = C_TRACE; c < kClasses; ++c)
+                if (cnt[c] > most) {
+                    most = cnt[c];
+                    phase = c;
+                }
+            if (phase == kClasses) break;  // no path in flight and nothing left to draw
+        }
+        // ---- up to 64 slots of that kind, in slot order
+        uint32_t n = 0;
+#pragma unroll
+        for (uint32_t base = 0; base < kPool; base += 64u) {
+            const uint32_t s = base + lane;
+            const bool is = s < kPool && (POOL(P_META, s) & 7u) == phase;
+            const unsigned long long bal = RRT_BALLOT(is);
+            const uint32_t rank = n + __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+            if (is && rank < 64u) list[rank] = s;
+            n += (uint32_t)__popcll(bal);
+        }
+        if (n > 64u) n = 64u;
+#ifdef RRT_PHASE_PROFILE
+        prof_phase = phase;
+#pragma unroll
+        for (uint32_t c = 0; c < kClasses; ++c)
+            if (phase == c) {
+                prof_steps[c] += 1;
+                prof_lanes[c] += n;
+            }
+#endif
+        __threadfence_block();
+        bool have = lane < n;
+        const uint32_t slot = have ? list[lane] : 0u;
+
+        if (phase == C_FREE) {
+            // ≙ main.rs:150-157, 227-229: the next samples of the wave's item (a new item when this one is used up)
+            if (next >= item_size) {
+                uint32_t item = 0;
+                if (lane == 0) item = atomicAdd(item_counter, 1u);
+                item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+                if (item >= ta.n_items) {
+                    exhausted = true;
+                    continue;
+                }
+                const uint32_t chunk = item / ta.n_t8, j = item % ta.n_t8;
+                const uint32_t tile32 = ta.tile_index + (j >> 4) * ta.tile_count;
+                x0 = (tile32 % ta.tiles_x) * 32u + ((j & 3u) << 3);
+                y0 = (tile32 / ta.tiles_x) * 32u + (((j >> 2) & 3u) << 3);
+                s0 = chunk * ta.chunk;
+                item_size = (ta.n_samples - s0 < ta.chunk ? ta.n_samples - s0 : ta.chunk) * 64u;
+                next = 0;
+            }
+            const uint32_t take = n < item_size - next ? n : item_size - next;
+            const uint32_t idx = next + lane;
+            const uint32_t px = x0 + (idx & 7u), py = y0 + ((idx >> 3) & 7u), smp = s0 + (idx >> 6);
+            const bool valid = lane < take && px < ta.W && py < ta.H;  // pixels beyond the frame's edge use up their samples, no slot
+            if (valid) {
+                Rng g = rng_seed(ta.seed, py * ta.W + px, ta.first_sample + smp);
+                const Ray r = camera_ray(sc.cam, px, py, ta.W, ta.H, g);
+                POOL(P_OX, slot) = __float_as_uint(r.o.x); POOL(P_OY, slot) = __float_as_uint(r.o.y); POOL(P_OZ, slot) = __float_as_uint(r.o.z);
+                POOL(P_DX, slot) = __float_as_uint(r.d.x); POOL(P_DY, slot) = __float_as_uint(r.d.y); POOL(P_DZ, slot) = __float_as_uint(r.d.z);
+                POOL(P_TX, slot) = __float_as_uint(1.0f); POOL(P_TY, slot) = __float_as_uint(1.0f); POOL(P_TZ, slot) = __float_as_uint(1.0f);
+                POOL(P_G0, slot) = g.s0; POOL(P_G1, slot) = g.s1;
+                POOL(P_PIX, slot) = py * ta.W + px;
+                POOL(P_META, slot) = C_TRACE | (smp << 13);
+                ++paths;
+            }
+            next += take;
+            const uint32_t made = (uint32_t)__popcll(RRT_BALLOT(valid));
+            cnt[C_FREE] -= made;
+            cnt[C_TRACE] += made;
+            __threadfence_block();
+            continue;
+        }
+
+        Ray r;
+        r.o = r.d = mk3(0.0f, 0.0f, 0.0f);
+        Rng g = {0u, 0u};
+        uint32_t meta = 0;
+        if (have) {
+            r.o = mk3(__uint_as_float(POOL(P_OX, slot)), __uint_as_float(POOL(P_OY, slot)), __uint_as_float(POOL(P_OZ, slot)));
+            r.d = mk3(__uint_as_float(POOL(P_DX, slot)), __uint_as_float(POOL(P_DY, slot)), __uint_as_float(POOL(P_DZ, slot)));
+            g.s0 = POOL(P_G0, slot);
+            g.s1 = POOL(P_G1, slot);
+            meta = POOL(P_META, slot);
+        }
+        const uint32_t depth = (meta >> 5) & 255u;
+
+        if (phase == C_TRACE) {
+            // ≙ aggregate.rs:24: the closest hit; then whatever decides which shading code the path needs
+            float harvest[kHarvestLights];
+#ifdef RRT_PHASE_PROFILE
+            unsigned long long sub0 = __builtin_readcyclecounter();
+#endif
+            const Hit hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST, kPoolSiftCap>(sc, have, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
+            uint32_t cls = C_END;
+#ifdef RRT_PHASE_PROFILE
+            unsigned long long sub1 = __builtin_readcyclecounter();
+            if (lane == 0) atomicAdd(&g_pool_prof[18], sub1 - sub0);
+#endif
+            if (have) {
+                ++rays;
+                if (HARVEST && (meta & 8u)) {  // aggregate.rs:79-89 for the previous bounce, now that this ray's light distances are known
+                    const f3 numerator = mk3(__uint_as_float(POOL(P_TX, slot)), __uint_as_float(POOL(P_TY, slot)), __uint_as_float(POOL(P_TZ, slot)));
+                    const float scatter_pdf = __uint_as_float(POOL(P_PDF_K, slot));
+                    const float pdf_val = mixture_value_harvested(sc, r, harvest) * 0.5f + scatter_pdf * 0.5f;  // pair_value, pdf.rs:117-119
+                    const f3 thr = numerator / pdf_val;
+                    POOL(P_TX, slot) = __float_as_uint(thr.x); POOL(P_TY, slot) = __float_as_uint(thr.y); POOL(P_TZ, slot) = __float_as_uint(thr.z);
+                }
+                uint32_t towards = 0u;
+                if (depth < ta.max_depth && hit.slot >= 0) {
+                    const uint32_t type = RRT_PLAIN_TYPE(__float_as_uint(sc.c_plain()[2 * hit.slot].w));
+                    if (type == RRT_MAT_LAMBERT) {
+                        const LightChoice ch = draw_light_choice(sc, g);  // pdf.rs:110, 122: the bounce's first draws
+                        cls = C_LCS;
+                        if (ch.towards_light) {
+                            towards = 16u;
+                            if (sc.c_lights()[ch.k].kind == RRT_KIND_TRIANGLE) cls = C_LTRI;
+                        }
+                        POOL(P_PDF_K, slot) = ch.k;
+                        POOL(P_G0, slot) = g.s0;
+                        POOL(P_G1, slot) = g.s1;
+                    } else if (type != RRT_MAT_DIFFUSE_LIGHT) {
+                        cls = C_GEN;
+                    }
+                }
+                POOL(P_T, slot) = __float_as_uint(hit.t);
+                POOL(P_HIT, slot) = hit.slot >= 0 ? ((((uint32_t)hit.slot + 1u) << 1) | (hit.det < 0.0f ? 1u : 0u)) : 0u;
+                POOL(P_META, slot) = (meta & ~(7u | 8u | 16u)) | cls | towards;
+            }
+#ifdef RRT_PHASE_PROFILE
+            if (lane == 0) atomicAdd(&g_pool_prof[19], __builtin_readcyclecounter() - sub1);
+#endif
+            cnt[C_TRACE] -= n;
+            cnt[C_END] += (uint32_t)__popcll(RRT_BALLOT(have && cls == C_END));
+            cnt[C_GEN] += (uint32_t)__popcll(RRT_BALLOT(have && cls == C_GEN));
+            cnt[C_LTRI] += (uint32_t)__popcll(RRT_BALLOT(have && cls == C_LTRI));
+            cnt[C_LCS] += (uint32_t)__popcll(RRT_BALLOT(have && cls == C_LCS));
+            __threadfence_block();
+            continue;
+        }
+
+        // ---- one of the shading kinds: aggregate.rs:26-104 after the query
+        bool done = false;
+        if (have) {
+            f3 thr = mk3(__uint_as_float(POOL(P_TX, slot)), __uint_as_float(POOL(P_TY, slot)), __uint_as_float(POOL(P_TZ, slot)));
+            const uint32_t hw = POOL(P_HIT, slot);
+            Hit hit;
+            hit.slot = (int)(hw >> 1) - 1;
+            hit.t = __uint_as_float(POOL(P_T, slot));
+            hit.u = hit.v = 0.0f;
+            hit.det = (hw & 1u) ? -1.0f : 1.0f;  // only the sign is used (by the hit properties)
+            const LightChoice chosen = {(meta & 16u) != 0u, POOL(P_PDF_K, slot)};
+            PendingPdf pend;
+            pend.active = false;
+            pend.numerator = mk3(0.0f, 0.0f, 0.0f);
+            pend.scatter_pdf = 0.0f;
+            f3 radiance;
+            done = shade<FEAT, HARVEST>(sc, hit, r, thr, g, depth, ta.max_depth, ta.bg, &radiance, &pend, &chosen);
+            if (done) {
+                const f3 c = thr * radiance;
+                float* q = slab + ((size_t)(meta >> 13) * frame_pixels + POOL(P_PIX, slot)) * 3;
+                q[0] = c.x;
+                q[1] = c.y;
+                q[2] = c.z;
+                POOL(P_META, slot) = C_FREE;
+            } else {
+                const bool pending = HARVEST && pend.active;
+                const f3 keep = pending ? pend.numerator : thr;  // a pending bounce parks its numerator where the throughput lives
+                POOL(P_OX, slot) = __float_as_uint(r.o.x); POOL(P_OY, slot) = __float_as_uint(r.o.y); POOL(P_OZ, slot) = __float_as_uint(r.o.z);
+                POOL(P_DX, slot) = __float_as_uint(r.d.x); POOL(P_DY, slot) = __float_as_uint(r.d.y); POOL(P_DZ, slot) = __float_as_uint(r.d.z);
+                POOL(P_TX, slot) = __float_as_uint(keep.x); POOL(P_TY, slot) = __float_as_uint(keep.y); POOL(P_TZ, slot) = __float_as_uint(keep.z);
+                POOL(P_G0, slot) = g.s0; POOL(P_G1, slot) = g.s1;
+                if (pending) POOL(P_PDF_K, slot) = __float_as_uint(pend.scatter_pdf);
+                POOL(P_META, slot) = (meta & ~(7u | 8u | 16u | (255u << 5))) | C_TRACE | (pending ? 8u : 0u) | ((depth + 1u) << 5);
+            }
+        }
+        const uint32_t ended = (uint32_t)__popcll(RRT_BALLOT(have && done));
+#pragma unroll
+        for (uint32_t c = C_END; c < kClasses; ++c)  // (constant indices: the counts stay in scalar registers)
+            if (phase == c) cnt[c] -= n;
+        cnt[C_FREE] += ended;
+        cnt[C_TRACE] += n - ended;
+        __threadfence_block();
+    }
+#undef POOL
+#ifdef RRT_PHASE_PROFILE
+    if (lane == 0)
+        for (uint32_t c = 0; c < kClasses; ++c) {
+            atomicAdd(&g_pool_prof[c], prof_steps[c]);
+            atomicAdd(&g_pool_prof[kClasses + c], prof_lanes[c]);
+            atomicAdd(&g_pool_prof[2 * kClasses + c], prof_cycles[c]);
+        }
 #endif
     if (counters) {
         for (int off = 32; off > 0; off >>= 1) {
@@ -560,6 +834,9 @@ struct rrt_scene {
     std::vector<void*> owned;
     float* slab = nullptr;  // per-sample radiance staging, allocated on first render
     float* static_slab = nullptr;  // this device's copy of `scratch` (rrt_render_device_noalloc), looked up once in rrt_scene_create
+    uint32_t* d_items = nullptr;   // k_trace_pool: the pass's item counter (one word, zeroed on the stream before every launch)
+    uint32_t wave_places = 0;      // k_trace_pool: waves the device holds at kPoolWaves per SIMD (the persistent grid's size)
+    bool pooling = true;           // shallow plain scenes take k_trace_pool (rrt_scene_set_pooling)
     size_t slab_bytes = 0;
     size_t slab_cap = kSlabCapBytes;
     uint32_t res_x = 0, res_y = 0, samples = 0, stack_depth = 1;
@@ -1004,6 +1281,34 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             return rrt_set_error(RRT_ERR_LIMIT, "a tree of at most 16 nodes (or a List) with more than 2^25 pair records");
         UP(pairs, (const float4*)pairs.data(), pairs.size() / 4);
     }
+    {
+        // Scenes whose textures are all Constant, without bump maps and media: one 32-byte record per slot with all that shading a
+        // hit needs (DScene::plain); other scenes do not use it and get an empty array.
+        bool plain = true;  // exactly when the plain kernel variants are chosen: see `features` below
+        for (uint32_t i = 0; plain && i < desc->n_slots; ++i) plain = RRT_INFO_KIND(desc->slots[i].info) != RRT_KIND_MEDIUM;
+        for (uint32_t i = 0; plain && i < desc->n_textures; ++i) plain = desc->textures[i].type == RRT_TEX_CONSTANT;
+        for (uint32_t i = 0; plain && i < desc->n_materials; ++i) plain = desc->materials[i].bump < 0 && desc->materials[i].type != RRT_MAT_ISOTROPIC;
+        std::vector<float> rec;
+        if (plain) {
+            rec.resize((size_t)desc->n_slots * 8, 0.0f);
+            for (uint32_t i = 0; i < desc->n_slots; ++i) {
+                const rrt_slot& sl = desc->slots[i];
+                const rrt_material& m = desc->materials[RRT_INFO_MATERIAL(sl.info)];
+                const uint32_t kind = RRT_INFO_KIND(sl.info);
+                float* q = &rec[(size_t)i * 8];
+                if (kind == RRT_KIND_TRIANGLE) std::memcpy(q, desc->tri_shade[i].nrm, 12);
+                if (kind == RRT_KIND_SPHERE && sl.aux >= (1u << 27)) return rrt_set_error(RRT_ERR_LIMIT, "more than 2^27 spheres");
+                const uint32_t bits = RRT_PLAIN_BITS(m.type, kind, kind == RRT_KIND_SPHERE ? sl.aux : 0u);
+                std::memcpy(q + 3, &bits, 4);
+                if (m.albedo >= 0) {  // Dielectric has no texture (its attenuation is 1: the colour is never read)
+                    const rrt_texture& t = desc->textures[m.albedo];
+                    q[4] = t.a; q[5] = t.b; q[6] = t.c;
+                }
+                q[7] = m.param;
+            }
+        }
+        UP(plain, (const float4*)rec.data(), rec.size() / 4);
+    }
     UP(slots, (const float4*)desc->slots, (size_t)desc->n_slots * 3);
     UP(tri_shade, (const float4*)desc->tri_shade, (size_t)desc->n_slots * 4);
     UP(spheres, desc->spheres, desc->n_spheres);
@@ -1042,6 +1347,15 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         if (desc->materials[i].bump >= 0) s->features |= F_BUMP | F_TEX;
         if (desc->materials[i].type == RRT_MAT_ISOTROPIC) s->features |= F_MEDIUM;
     }
+    {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, 256));
+        s->owned.push_back(p);
+        s->d_items = (uint32_t*)p;
+        int cus = 0;
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
+        s->wave_places = (uint32_t)(cus > 0 ? cus : 256) * 4u * kPoolWaves;
+    }
     s->upload_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
     *out = owner.release();
     return RRT_OK;
@@ -1077,6 +1391,12 @@ int rrt_scene_upload_seconds(const rrt_scene* s, double* seconds) {
 int rrt_scene_set_staging_limit(rrt_scene* s, uint64_t bytes) {
     if (!s) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_set_staging_limit: NULL scene");
     s->slab_cap = bytes ? (size_t)bytes : kSlabCapBytes;
+    return RRT_OK;
+}
+
+int rrt_scene_set_pooling(rrt_scene* s, int enable) {
+    if (!s) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_set_pooling: NULL scene");
+    s->pooling = enable != 0;
     return RRT_OK;
 }
 
@@ -1297,6 +1617,23 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
         if (items > 0x7fffffffull) return rrt_set_error(RRT_ERR_LIMIT, "rrt_render: too many work items in one pass");
         const dim3 grid((unsigned)items);
         float* const pass_slab = static_staging ? slab : s->slab;
+        // shallow trees, plain feature set: the pooled schedule (k_trace_pool) - a persistent grid that hands the items out itself
+        if (s->pooling && !s->deep && (need & ~kPlain) == 0 && ta.max_depth <= kPoolMaxDepth && ta.n_samples <= kPoolMaxSamples) {
+            ta.n_items = (uint32_t)items;
+            const dim3 pgrid((unsigned)(items < s->wave_places ? items : s->wave_places));
+            if (s->harvest) ta.stack_depth = 0;  // a single leaf: the walk never pushes
+            const size_t plds = (size_t)kTraceBlock * ta.stack_depth * sizeof(uint32_t) + kPoolBytesPerWave;
+            HIP_TRY(hipMemsetAsync(s->d_items, 0, sizeof(uint32_t), st));
+#define RRT_LAUNCH_POOL(MODE, HARV) hipLaunchKernelGGL((k_trace_pool<MODE, kPlain, HARV>), pgrid, dim3(kTraceBlock), plds, st, s->d, ta, pass_slab, cnt, s->d_items)
+            if (p->aabb_mode == RRT_AABB_REFERENCE) {
+                if (s->harvest) RRT_LAUNCH_POOL(RRT_AABB_REFERENCE, true);
+                else RRT_LAUNCH_POOL(RRT_AABB_REFERENCE, false);
+            } else {
+                if (s->harvest) RRT_LAUNCH_POOL(RRT_AABB_TIGHT, true);
+                else RRT_LAUNCH_POOL(RRT_AABB_TIGHT, false);
+            }
+#undef RRT_LAUNCH_POOL
+        } else {
 #define RRT_LAUNCH(MODE, FEAT) hipLaunchKernelGGL((k_trace<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt)
 #define RRT_LAUNCH_STREAM(MODE, FEAT) hipLaunchKernelGGL((k_trace_stream<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt)
 #define RRT_PICK(MODE)                                                               \
@@ -1316,6 +1653,7 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
             else RRT_LAUNCH_STREAM(kAabbClean, F_ALL);
         } else if (p->aabb_mode == RRT_AABB_REFERENCE) RRT_PICK(RRT_AABB_REFERENCE);
         else RRT_PICK(RRT_AABB_TIGHT);
+        }
 #undef RRT_PICK
 #undef RRT_LAUNCH
 #undef RRT_LAUNCH_STREAM
@@ -1676,6 +2014,14 @@ int rrt_resolve_rgb8(const float* rgb_sum, uint32_t W, uint32_t H, uint32_t spp,
 }
 
 #ifdef RRT_PHASE_PROFILE
+// profiling build only: reads and clears k_trace_pool's per-kind counters (steps[6], paths served[6], cycles[6])
+extern "C" int rrt_profile_read_pool(uint64_t* out18) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out18, HIP_SYMBOL(g_pool_prof), 20 * 8));
+    uint64_t zero[20] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pool_prof), zero, 20 * 8));
+    return RRT_OK;
+}
 // profiling build only: reads and clears the traversal counters
 extern "C" int rrt_profile_read(uint64_t* out8) {
     HIP_TRY(hipDeviceSynchronize());

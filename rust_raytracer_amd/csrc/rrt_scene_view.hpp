@@ -30,6 +30,9 @@ struct DScene {
                               // unused; a link is an inner node's index, kLinkLeaf | (pairs - 1) << 28 | first pair, or kLinkNone
     const float4* pairs;      // kPairQuads x float4 per two consecutive primitives of a leaf (see triangle_pair_eval)
     const float4* slots;      // 3 x float4 per rrt_slot
+    const float4* plain;      // scenes whose textures are all Constant, without bump maps and media: 2 x float4 per slot holding all
+                              // that shading a hit on it needs - (unit normal | -, kind / material type / sphere index), (the
+                              // material's colour, its roughness or refractive index) - one fetch instead of slot -> material -> texture
     const float4* tri_shade;  // 4 x float4 per rrt_tri_shade
     const rrt_sphere* spheres;
     const rrt_medium* media;
@@ -46,6 +49,7 @@ struct DScene {
     RRT_DEV cv4p c_nodes() const { return (cv4p)(const void*)nodes; }
     RRT_DEV cv4p c_pairs() const { return (cv4p)(const void*)pairs; }
     RRT_DEV cv4p c_slots() const { return (cv4p)(const void*)slots; }
+    RRT_DEV cv4p c_plain() const { return (cv4p)(const void*)plain; }
     RRT_DEV cv4p c_tri_shade() const { return (cv4p)(const void*)tri_shade; }
     RRT_DEV cv4p c_btris() const { return (cv4p)(const void*)btris; }
     RRT_DEV cv4p c_btri_shade() const { return (cv4p)(const void*)btri_shade; }

@@ -148,16 +148,28 @@ RRT_DEV float cosine_value(f3 normal, const Ray& r) {  // pdf.rs:51-58
 // mixture or the cosine lobe; Mixture::generate (pdf.rs:109-114) picks a member.  Sphere lights (random_to_sphere) and the
 // cosine lobe (random_cosine_direction) are both "two draws, one sincos, one orthonormal basis", so they share that code:
 // only the basis axis and the (z, sin-radius) pair differ.  Draw order is the reference's: [pair], [member], r1, r2.
-RRT_DEV f3 sample_scatter_direction(const DScene& sc, f3 n, f3 from, Rng& g) {
-    bool towards_light = false;
-    uint32_t k = 0;
+// The first draws of that branch - pair_generate's coin (pdf.rs:122) and Mixture::generate's member (pdf.rs:110) - as a step of
+// its own, for callers that sort paths by the outcome before they shade them.
+struct LightChoice {
+    bool towards_light;
+    uint32_t k;
+};
+RRT_DEV LightChoice draw_light_choice(const DScene& sc, Rng& g) {
+    LightChoice c = {false, 0u};
     if (sc.n_lights > 0) {
         float xi = rng_f32(g);
         if (xi < 0.5f) {
-            towards_light = true;
-            k = rng_index(g, sc.n_lights);
+            c.towards_light = true;
+            c.k = rng_index(g, sc.n_lights);
         }
     }
+    return c;
+}
+// `chosen`: the outcome of draw_light_choice() when the caller has made those draws already (nullptr: they are made here).
+RRT_DEV f3 sample_scatter_direction(const DScene& sc, f3 n, f3 from, Rng& g, const LightChoice* chosen = nullptr) {
+    const LightChoice choice = chosen ? *chosen : draw_light_choice(sc, g);
+    const bool towards_light = choice.towards_light;
+    const uint32_t k = choice.k;
     float r1 = rng_f32(g);
     float r2 = rng_f32(g);
     bool tri_light = false;
@@ -195,6 +207,12 @@ RRT_DEV f3 sample_scatter_direction(const DScene& sc, f3 n, f3 from, Rng& g) {
     if (sphere_light) d = xform_vec((cf1p)s->l2w, d);
     return d;
 }
+
+// DScene::plain, word 3 of a slot's first quad: bits 0..2 material type, 3..4 primitive kind, 5.. sphere index
+#define RRT_PLAIN_TYPE(bits) ((bits) & 7u)
+#define RRT_PLAIN_KIND(bits) (((bits) >> 3) & 3u)
+#define RRT_PLAIN_AUX(bits) ((bits) >> 5)
+#define RRT_PLAIN_BITS(type, kind, aux) ((type) | ((kind) << 3) | ((aux) << 5))
 
 // ---- materials (material.rs:15-54) -----------------------------------------------------------------------------------------
 RRT_DEV f3 reflect_ref(f3 v, f3 n) { return v - 2.0f * dot3(v, n) * n; }
@@ -260,28 +278,41 @@ struct PendingPdf {
 };
 template <uint32_t FEAT, bool HARVEST = false>
 RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, uint32_t depth, uint32_t max_depth, uint32_t bg, f3* radiance,
-                   PendingPdf* pend = nullptr) {
+                   PendingPdf* pend = nullptr, const LightChoice* chosen = nullptr) {
     if (!(depth < max_depth && hit.slot >= 0)) {
         *radiance = background(bg, r);
         return true;
     }
-    uint32_t mat_id;
-    HitProps hp = slot_props<FEAT>(sc, hit, r, &mat_id);
-    if (RRT_DUP & 2) {
-        Ray r2 = r;
-        RRT_OPAQUE(r2.o.x);
-        uint32_t m2;
-        HitProps h2 = slot_props<FEAT>(sc, hit, r2, &m2);
-        RRT_KEEP(h2.p.x); RRT_KEEP(h2.p.y); RRT_KEEP(h2.p.z); RRT_KEEP(h2.n.x); RRT_KEEP(h2.n.y); RRT_KEEP(h2.n.z);
+    // Plain scenes (constant textures, no bump maps, no media) keep one record per slot with everything below: see DScene::plain.
+    constexpr bool kPlainRecord = (FEAT & (F_TEX | F_BUMP | F_MEDIUM)) == 0;
+    HitProps hp;
+    struct { uint32_t type; int32_t albedo, bump; float param; } m;
+    f3 plain_colour = mk3(0.0f, 0.0f, 0.0f);
+    if (kPlainRecord) {
+        const v4f s0 = sc.c_plain()[2 * hit.slot], s1 = sc.c_plain()[2 * hit.slot + 1];
+        const uint32_t bits = __float_as_uint(s0.w);
+        m = {RRT_PLAIN_TYPE(bits), -1, -1, s1.w};
+        plain_colour = xyz(s1);
+        if (!(FEAT & F_SPHERE) || RRT_PLAIN_KIND(bits) == RRT_KIND_TRIANGLE) {  // triangle_props without texture coordinates
+            hp.p = point_at(r, hit.t);
+            hp.n = hit.det < 0.0f ? -xyz(s0) : xyz(s0);
+            hp.u = hp.v = 0.0f;
+            hp.pu = hp.pv = mk3(0.0f, 0.0f, 0.0f);
+        } else {
+            hp = sphere_props(sc.c_spheres() + RRT_PLAIN_AUX(bits), r, hit.t, false);
+        }
+    } else {
+        uint32_t mat_id;
+        hp = slot_props<FEAT>(sc, hit, r, &mat_id);
+        if (FEAT & (F_TEX | F_BUMP)) {
+            hp.u = clampf(hp.u, 0.0f, 1.0f);  // aggregate.rs:31
+            hp.v = clampf(hp.v, 0.0f, 1.0f);
+        }
+        const cmaterial_p mp = sc.c_materials() + mat_id;
+        m = {mp->type, mp->albedo, mp->bump, mp->param};
     }
-    if (FEAT & (F_TEX | F_BUMP)) {
-        hp.u = clampf(hp.u, 0.0f, 1.0f);  // aggregate.rs:31
-        hp.v = clampf(hp.v, 0.0f, 1.0f);
-    }
-    const cmaterial_p mp = sc.c_materials() + mat_id;
-    struct { uint32_t type; int32_t albedo, bump; float param; } m = {mp->type, mp->albedo, mp->bump, mp->param};
     if (m.type == RRT_MAT_DIFFUSE_LIGHT) {  // material.rs:229-231: emission ends the path
-        *radiance = albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
+        *radiance = kPlainRecord ? plain_colour : albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
         return true;
     }
     if (m.type == RRT_MAT_DIELECTRIC) {  // material.rs:172-207
@@ -305,17 +336,6 @@ RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, ui
             if (rng_f32(g) < reflect_prob) out = reflect_ref(unit_dir, n_use);
             else out = refract_ref(unit_dir, n_use, eta);
         }
-        if (RRT_DUP & 64) {
-            f3 u2 = unit_dir;
-            RRT_OPAQUE(u2.x);
-            float c2 = fmin_ref(dot3(-u2, n_use), 1.0f);
-            float s2 = __builtin_sqrtf(1.0f - c2 * c2);
-            f3 o2;
-            if (eta * s2 > 1.0f) o2 = reflect_ref(u2, n_use);
-            else if (schlick_ref(c2, eta) > 0.5f) o2 = reflect_ref(u2, n_use);
-            else o2 = refract_ref(u2, n_use, eta);
-            RRT_KEEP(o2.x); RRT_KEEP(o2.y); RRT_KEEP(o2.z);
-        }
         thr = thr * mk3(1.0f, 1.0f, 1.0f);
         r.o = hp.p;
         r.d = out;
@@ -323,7 +343,7 @@ RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, ui
     }
     if ((FEAT & F_MEDIUM) && m.type == RRT_MAT_ISOTROPIC) {  // volume.rs:27-35
         f3 out = unit_sphere_random(g);
-        f3 att = albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
+        f3 att = kPlainRecord ? plain_colour : albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
         thr = thr * att;
         r.o = hp.p;
         r.d = out;
@@ -334,23 +354,17 @@ RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, ui
     if (m.type == RRT_MAT_METAL) {  // material.rs:145-160
         f3 reflected = reflect_ref(norm3(r.d), n);
         f3 out = reflected + m.param * unit_sphere_random(g);
-        f3 att = albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
+        f3 att = kPlainRecord ? plain_colour : albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
         thr = thr * att;
         r.o = hp.p;
         r.d = out;
         return false;
     }
     // Lambert (material.rs:98-110) + the PDF branch of trace (aggregate.rs:57-90)
-    f3 att = albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
+    f3 att = kPlainRecord ? plain_colour : albedo_value<FEAT>(sc, m.albedo, hp.u, hp.v, hp.p);
     Ray scattered;
     scattered.o = hp.p;
-    if (RRT_DUP & 4) {
-        Rng g2 = g;
-        RRT_OPAQUE(g2.s0);
-        f3 d2 = sample_scatter_direction(sc, n, hp.p, g2);
-        RRT_KEEP(d2.x); RRT_KEEP(d2.y); RRT_KEEP(d2.z);
-    }
-    scattered.d = sample_scatter_direction(sc, n, hp.p, g);
+    scattered.d = sample_scatter_direction(sc, n, hp.p, g, chosen);
     const float scatter_pdf = cosine_value(n, scattered);
     if (HARVEST) {  // n_lights > 0 here; the division by pair_value happens after the next closest-hit query
         pend->active = true;
@@ -362,18 +376,6 @@ RRT_DEV bool shade(const DScene& sc, const Hit& hit, Ray& r, f3& thr, Rng& g, ui
     float pdf_val;
     if (sc.n_lights > 0) pdf_val = mixture_value(sc, scattered) * 0.5f + scatter_pdf * 0.5f;  // pair_value, pdf.rs:117-119
     else pdf_val = scatter_pdf;
-    if (RRT_DUP & 8) {
-        Ray s2 = scattered;
-        RRT_OPAQUE(s2.d.x);
-        float m2 = mixture_value(sc, s2);
-        RRT_KEEP(m2);
-    }
-    if (RRT_DUP & 16) {
-        Ray s2 = scattered;
-        RRT_OPAQUE(s2.d.x);
-        float m2 = cosine_value(n, s2);
-        RRT_KEEP(m2);
-    }
     thr = (thr * (att * scatter_pdf)) / pdf_val;
     r = scattered;
     return false;

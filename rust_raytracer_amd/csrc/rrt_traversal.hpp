@@ -18,14 +18,6 @@ enum : uint32_t {
 };
 
 
-// Cost-measurement builds only (-DRRT_DUP=<bits>): the named piece is computed a second time on inputs the compiler
-// must treat as new, and the copy's result is kept alive; results are unchanged, the time difference is the piece's cost.
-#ifndef RRT_DUP
-#define RRT_DUP 0
-#endif
-#define RRT_OPAQUE(x) asm volatile("" : "+v"(x))
-#define RRT_KEEP(x) asm volatile("" ::"v"(x))
-
 #ifdef RRT_PHASE_PROFILE
 // profiling build only: per-lane node visits, per-lane pair tests, wave-level node steps, wave-level pair steps
 __device__ unsigned long long g_prof[8];  // [4..7]: sift phase (filter steps, items, dense groups, phases), counted per wave
@@ -446,17 +438,18 @@ RRT_DEV void triangle_uvdet(f3 v0, f3 e1, f3 e2, const Ray& r, float* u, float* 
 // reports, per light, the distance at which the ray meets the light's own primitive (any distance in (t_min, t_max), whether
 // or not something nearer hides it, and whether or not the leaf's box test let the ray in: Shape::pdf asks the shape, not
 // the tree), and the caller finishes the previous bounce's throughput from that.  Same tests, same numbers, run once.
-constexpr uint32_t kSiftCap = 512;
+constexpr uint32_t kSiftCap = 512;  // items the candidate list holds (the CAP template argument below; a caller short of LDS passes less)
 constexpr uint32_t kHarvestLights = 4;
-constexpr uint32_t kSiftBytesPerWave = 64 * 8 + kSiftCap * 4;
+constexpr uint32_t sift_bytes(uint32_t cap) { return 64 * 8 + cap * 4; }
+constexpr uint32_t kSiftBytesPerWave = sift_bytes(kSiftCap);
 constexpr uint32_t kHarvestBytesPerWave = 64 * kHarvestLights * 4;
 #define RRT_PAIR_LIGHT(info) (((info) >> 24) & 15u)  // device-only bits of a pair record's info words: light number + 1
 
-template <uint32_t FEAT, bool HARVEST>
+template <uint32_t FEAT, bool HARVEST, uint32_t CAP = kSiftCap>
 RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, const uint32_t* items, uint32_t n_items,
                         unsigned long long* best) {
     constexpr uint32_t kLaneShift = HARVEST ? 7 : 6;  // HARVEST items carry one more bit: the owner only wants its lights
-    float* light_t = (float*)((unsigned char*)best + kSiftBytesPerWave);
+    float* light_t = (float*)((unsigned char*)best + sift_bytes(CAP));
     const uint32_t lane = threadIdx.x & 63u;
     const cv4p cpairs = sc.c_pairs();
     __threadfence_block();
@@ -525,7 +518,7 @@ RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max
     __threadfence_block();
 }
 
-template <int AABB_MODE, uint32_t FEAT, bool HARVEST = false>
+template <int AABB_MODE, uint32_t FEAT, bool HARVEST = false, uint32_t CAP = kSiftCap>
 RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack,
                              uint32_t stride, unsigned char* area, float* harvest = nullptr) {
     // Must be called by all 64 lanes of the wave (the dense phase addresses lanes by number); lanes without a ray pass
@@ -555,7 +548,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
     bool running = active, pending = false;
     bool lights_only = false;  // HARVEST: the leaf's box test failed, so only the lights' own primitives are of interest
     uint32_t first_pair = 0, n_pairs = 0;
-    float* light_t = (float*)(area + kSiftBytesPerWave);
+    float* light_t = (float*)(area + sift_bytes(CAP));
     if (HARVEST)
         for (uint32_t i = 0; i < kHarvestLights; ++i) harvest[i] = -1.0f;
     for (;;) {
@@ -617,10 +610,10 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                 }
                 n_items += (uint32_t)__popcll(bal);
                 RRT_COUNT(prof_filter, 1);
-                if (n_items > kSiftCap - 64u) {
+                if (n_items > CAP - 64u) {
                     RRT_COUNT(prof_items, n_items);
                     RRT_COUNT(prof_groups, (n_items + 63u) / 64u);
-                    sift_flush<FEAT, HARVEST>(sc, r, t_min, t_max, key, depth, items, n_items, best);
+                    sift_flush<FEAT, HARVEST, CAP>(sc, r, t_min, t_max, key, depth, items, n_items, best);
                     n_items = 0;
                 }
             }
@@ -629,7 +622,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
         RRT_COUNT(prof_items, n_items);
         RRT_COUNT(prof_groups, (n_items + 63u) / 64u);
         RRT_COUNT(prof_phases, 1);
-        sift_flush<FEAT, HARVEST>(sc, r, t_min, t_max, key, depth, items, n_items, best);
+        sift_flush<FEAT, HARVEST, CAP>(sc, r, t_min, t_max, key, depth, items, n_items, best);
         if (pending) {
             if (HARVEST)
                 for (uint32_t i = 0; i < kHarvestLights; ++i) harvest[i] = light_t[lane * kHarvestLights + i];

@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""Per-kind split of k_trace_pool from a library built with -DRRT_PHASE_PROFILE (RRT_LIB points at it):
+python tools/perf_pool_phase.py SCENE W H SPP BG"""
+import ctypes, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import rust_raytracer_amd as rrt
+name, W, H, spp, bg = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+sc = rrt.Scene.load(os.path.join(ROOT, "tests", "golden", "assets", name + ".json"), width=W, height=H, samples=spp)
+img = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
+cnt = torch.zeros(16, dtype=torch.int64, device="cuda")
+sc.render_device(img.data_ptr(), cnt.data_ptr(), 0, samples=spp, background=bg)
+torch.cuda.synchronize()
+out = np.zeros(20, dtype=np.uint64)
+rrt.lib().rrt_profile_read_pool(ctypes.c_void_p(out.ctypes.data))
+steps, lanes, cyc = out[:6].astype(float), out[6:12].astype(float), out[12:18].astype(float)
+c = cnt.cpu().numpy()
+print("rays %d paths %d" % (c[0], c[1]))
+for i, nm in enumerate(["FREE", "TRACE", "END", "GEN", "LTRI", "LCS"]):
+    if steps[i]:
+        print("%-6s steps %10d  paths/step %5.1f  cycles %5.1f %%  cycles/step %8.0f" % (nm, steps[i], lanes[i] / steps[i], 100 * cyc[i] / cyc.sum(), cyc[i] / steps[i]))
+print("mean paths per step %.1f; steps per ray %.3f" % (lanes.sum() / steps.sum(), steps.sum() / c[0]))
+print("TRACE: closest hit %.0f cycles/step, density + classification %.0f cycles/step" % (out[18] / steps[1], out[19] / steps[1]))

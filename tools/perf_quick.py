@@ -18,6 +18,8 @@ bg = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 3
 torch.cuda.set_device(0)
 sc = rrt.Scene.load(os.path.join(ROOT, "tests", "golden", "assets", name), width=W, height=H, samples=spp)
+if os.environ.get("RRT_POOLING") == "0":
+    sc.set_pooling(False)  # one path per lane (k_trace) instead of the pooled schedule
 img = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
 cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
 st = torch.cuda.current_stream()
