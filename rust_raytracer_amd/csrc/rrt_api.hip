@@ -196,9 +196,9 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
 // pulls those 64 into registers, runs that one piece of code at full width and files the paths under what they wait for next:
 //   FREE   a slot without a path            -> draw a sample, make the camera ray                     -> TRACE
 //   TRACE  has a ray                        -> closest hit (sifting query), finish the last bounce's density, look up the
-//                                              material, for Lambert make the light-or-lobe draws    -> END / GEN / LTRI / LCS
-//   END    missed, hit a light, depth limit -> radiance, store the sample                             -> FREE
-//   GEN    glass, metal, phase function     -> shade                                                  -> TRACE
+//                                              material; a path that missed, hit a light or reached the depth limit stores
+//                                              its sample; for Lambert make the light-or-lobe draws  -> FREE / GEN / LTRI / LCS
+//   GEN    glass, metal                     -> shade                                                  -> TRACE
 //   LTRI   Lambert, towards a triangle light-> shade                                                  -> TRACE
 //   LCS    Lambert, cosine lobe or sphere light (one sincos / basis block, see sample_scatter_direction) -> TRACE
 // The draws of a path are made in the reference's order whatever the schedule (the light-or-lobe draws are the first of their
@@ -215,10 +215,10 @@ __device__ unsigned long long g_pool_prof[24];  // profiling build only: per kin
 #define RRT_POOL_WAVES 4
 #endif
 constexpr uint32_t kPool = RRT_POOL;    // paths per wave: 16 x 128 x 4 B = 8 KB; with the query's work area 10 KB: four waves per SIMD
-constexpr uint32_t kPoolSiftCap = 128;  // candidate list of the sifting query (a wave iteration lists about 120, flushed in two parts)
+constexpr uint32_t kPoolSiftCap = 192;  // candidate list of the sifting query: flushed early beyond 128 candidates (a step lists about 110)
 constexpr uint32_t kPoolWaves = RRT_POOL_WAVES;  // waves per SIMD the LDS request leaves room for
 enum : uint32_t { P_OX, P_OY, P_OZ, P_DX, P_DY, P_DZ, P_TX, P_TY, P_TZ, P_G0, P_G1, P_PIX, P_META, P_PDF_K, P_T, P_HIT, kPoolFields };
-enum : uint32_t { C_FREE = 0, C_TRACE = 1, C_END = 2, C_GEN = 3, C_LTRI = 4, C_LCS = 5, kClasses = 6 };
+enum : uint32_t { C_FREE = 0, C_TRACE = 1, C_GEN = 2, C_LTRI = 3, C_LCS = 4, kClasses = 5 };
 // P_META: bits 0..2 class, 3 a diffuse bounce's density is pending, 4 the light-or-lobe draw chose a light, 5..12 depth, 13..31 sample
 constexpr uint32_t kPoolMaxDepth = 255, kPoolMaxSamples = 1u << 19;
 constexpr size_t kPoolBytesPerWave = sift_bytes(kPoolSiftCap) + kHarvestBytesPerWave + (size_t)kPoolFields * kPool * 4;
@@ -235,13 +235,13 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
 #define POOL(f, slot) pool[(f) * kPool + (slot)]
     for (uint32_t s = lane; s < kPool; s += 64u) POOL(P_META, s) = C_FREE;
     __threadfence_block();
-    uint32_t cnt[kClasses] = {kPool, 0u, 0u, 0u, 0u, 0u};  // wave-uniform
+    uint32_t cnt[kClasses] = {kPool, 0u, 0u, 0u, 0u};  // wave-uniform
     uint32_t x0 = 0, y0 = 0, s0 = 0, item_size = 0, next = 0;  // the item samples are drawn from, and the next undrawn one
     bool exhausted = false;                                    // no items left in the frame
     unsigned long long rays = 0, paths = 0;
     const size_t frame_pixels = (size_t)ta.W * ta.H;
 #ifdef RRT_PHASE_PROFILE
-    unsigned long long prof_steps[kClasses] = {0, 0, 0, 0, 0, 0}, prof_lanes[kClasses] = {0, 0, 0, 0, 0, 0}, prof_cycles[kClasses] = {0, 0, 0, 0, 0, 0};
+    unsigned long long prof_steps[kClasses] = {0, 0, 0, 0, 0}, prof_lanes[kClasses] = {0, 0, 0, 0, 0}, prof_cycles[kClasses] = {0, 0, 0, 0, 0};
     unsigned long long prof_tick = __builtin_readcyclecounter();
     uint32_t prof_phase = kClasses;
 #define RRT_POOL_PROFILE_STEP()                                                         \
@@ -259,8 +259,7 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
         // samples while slots are free, else the fullest kind
         uint32_t phase = kClasses;
         const bool can_draw = !exhausted && cnt[C_FREE] != 0u;
-        if (cnt[C_END] >= 64u) phase = C_END;
-        else if (cnt[C_LCS] >= 64u) phase = C_LCS;
+        if (cnt[C_LCS] >= 64u) phase = C_LCS;
         else if (cnt[C_LTRI] >= 64u) phase = C_LTRI;
         else if (cnt[C_GEN] >= 64u) phase = C_GEN;
         else if (can_draw && cnt[C_FREE] >= 64u) phase = C_FREE;
@@ -358,28 +357,24 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
         if (phase == C_TRACE) {
             // ≙ aggregate.rs:24: the closest hit; then whatever decides which shading code the path needs
             float harvest[kHarvestLights];
-#ifdef RRT_PHASE_PROFILE
-            unsigned long long sub0 = __builtin_readcyclecounter();
-#endif
             const Hit hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST, kPoolSiftCap>(sc, have, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
-            uint32_t cls = C_END;
-#ifdef RRT_PHASE_PROFILE
-            unsigned long long sub1 = __builtin_readcyclecounter();
-            if (lane == 0) atomicAdd(&g_pool_prof[18], sub1 - sub0);
-#endif
+            uint32_t cls = C_FREE;
             if (have) {
                 ++rays;
-                if (HARVEST && (meta & 8u)) {  // aggregate.rs:79-89 for the previous bounce, now that this ray's light distances are known
-                    const f3 numerator = mk3(__uint_as_float(POOL(P_TX, slot)), __uint_as_float(POOL(P_TY, slot)), __uint_as_float(POOL(P_TZ, slot)));
+                f3 thr = mk3(__uint_as_float(POOL(P_TX, slot)), __uint_as_float(POOL(P_TY, slot)), __uint_as_float(POOL(P_TZ, slot)));
+                const bool pending = HARVEST && (meta & 8u) != 0u;
+                if (pending) {  // aggregate.rs:79-89 for the previous bounce, now that this ray's light distances are known (thr held the numerator)
                     const float scatter_pdf = __uint_as_float(POOL(P_PDF_K, slot));
                     const float pdf_val = mixture_value_harvested(sc, r, harvest) * 0.5f + scatter_pdf * 0.5f;  // pair_value, pdf.rs:117-119
-                    const f3 thr = numerator / pdf_val;
-                    POOL(P_TX, slot) = __float_as_uint(thr.x); POOL(P_TY, slot) = __float_as_uint(thr.y); POOL(P_TZ, slot) = __float_as_uint(thr.z);
+                    thr = thr / pdf_val;
                 }
                 uint32_t towards = 0u;
+                f3 radiance = mk3(0.0f, 0.0f, 0.0f);
                 if (depth < ta.max_depth && hit.slot >= 0) {
                     const uint32_t type = RRT_PLAIN_TYPE(__float_as_uint(sc.c_plain()[2 * hit.slot].w));
-                    if (type == RRT_MAT_LAMBERT) {
+                    if (type == RRT_MAT_DIFFUSE_LIGHT) {  // material.rs:229-231: emission ends the path
+                        radiance = xyz(sc.c_plain()[2 * hit.slot + 1]);
+                    } else if (type == RRT_MAT_LAMBERT) {
                         const LightChoice ch = draw_light_choice(sc, g);  // pdf.rs:110, 122: the bounce's first draws
                         cls = C_LCS;
                         if (ch.towards_light) {
@@ -389,19 +384,30 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
                         POOL(P_PDF_K, slot) = ch.k;
                         POOL(P_G0, slot) = g.s0;
                         POOL(P_G1, slot) = g.s1;
-                    } else if (type != RRT_MAT_DIFFUSE_LIGHT) {
+                    } else {
                         cls = C_GEN;
                     }
+                } else {
+                    radiance = background(ta.bg, r);  // aggregate.rs:104: a miss, or the depth limit
                 }
-                POOL(P_T, slot) = __float_as_uint(hit.t);
-                POOL(P_HIT, slot) = hit.slot >= 0 ? ((((uint32_t)hit.slot + 1u) << 1) | (hit.det < 0.0f ? 1u : 0u)) : 0u;
-                POOL(P_META, slot) = (meta & ~(7u | 8u | 16u)) | cls | towards;
+                if (cls == C_FREE) {  // the path ends here and its sample is stored (main.rs:244-245): no shading step needed
+                    const f3 c = thr * radiance;
+                    float* q = slab + ((size_t)(meta >> 13) * frame_pixels + POOL(P_PIX, slot)) * 3;
+                    q[0] = c.x;
+                    q[1] = c.y;
+                    q[2] = c.z;
+                    POOL(P_META, slot) = C_FREE;
+                } else {
+                    if (pending) {
+                        POOL(P_TX, slot) = __float_as_uint(thr.x); POOL(P_TY, slot) = __float_as_uint(thr.y); POOL(P_TZ, slot) = __float_as_uint(thr.z);
+                    }
+                    POOL(P_T, slot) = __float_as_uint(hit.t);
+                    POOL(P_HIT, slot) = (((uint32_t)hit.slot + 1u) << 1) | (hit.det < 0.0f ? 1u : 0u);
+                    POOL(P_META, slot) = (meta & ~(7u | 8u | 16u)) | cls | towards;
+                }
             }
-#ifdef RRT_PHASE_PROFILE
-            if (lane == 0) atomicAdd(&g_pool_prof[19], __builtin_readcyclecounter() - sub1);
-#endif
             cnt[C_TRACE] -= n;
-            cnt[C_END] += (uint32_t)__popcll(RRT_BALLOT(have && cls == C_END));
+            cnt[C_FREE] += (uint32_t)__popcll(RRT_BALLOT(have && cls == C_FREE));
             cnt[C_GEN] += (uint32_t)__popcll(RRT_BALLOT(have && cls == C_GEN));
             cnt[C_LTRI] += (uint32_t)__popcll(RRT_BALLOT(have && cls == C_LTRI));
             cnt[C_LCS] += (uint32_t)__popcll(RRT_BALLOT(have && cls == C_LCS));
@@ -446,7 +452,7 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
         }
         const uint32_t ended = (uint32_t)__popcll(RRT_BALLOT(have && done));
 #pragma unroll
-        for (uint32_t c = C_END; c < kClasses; ++c)  // (constant indices: the counts stay in scalar registers)
+        for (uint32_t c = C_GEN; c < kClasses; ++c)  // (constant indices: the counts stay in scalar registers)
             if (phase == c) cnt[c] -= n;
         cnt[C_FREE] += ended;
         cnt[C_TRACE] += n - ended;
@@ -2014,12 +2020,12 @@ int rrt_resolve_rgb8(const float* rgb_sum, uint32_t W, uint32_t H, uint32_t spp,
 }
 
 #ifdef RRT_PHASE_PROFILE
-// profiling build only: reads and clears k_trace_pool's per-kind counters (steps[6], paths served[6], cycles[6])
+// profiling build only: reads and clears k_trace_pool's per-kind counters (steps[5], paths served[5], cycles[5])
 extern "C" int rrt_profile_read_pool(uint64_t* out18) {
     HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpyFromSymbol(out18, HIP_SYMBOL(g_pool_prof), 20 * 8));
-    uint64_t zero[20] = {0};
-    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pool_prof), zero, 20 * 8));
+    HIP_TRY(hipMemcpyFromSymbol(out18, HIP_SYMBOL(g_pool_prof), 3 * kClasses * 8));
+    uint64_t zero[3 * kClasses] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pool_prof), zero, 3 * kClasses * 8));
     return RRT_OK;
 }
 // profiling build only: reads and clears the traversal counters

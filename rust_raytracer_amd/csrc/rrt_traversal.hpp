@@ -439,7 +439,7 @@ RRT_DEV void triangle_uvdet(f3 v0, f3 e1, f3 e2, const Ray& r, float* u, float* 
 // or not something nearer hides it, and whether or not the leaf's box test let the ray in: Shape::pdf asks the shape, not
 // the tree), and the caller finishes the previous bounce's throughput from that.  Same tests, same numbers, run once.
 constexpr uint32_t kSiftCap = 512;  // items the candidate list holds (the CAP template argument below; a caller short of LDS passes less)
-constexpr uint32_t kHarvestLights = 4;
+constexpr uint32_t kHarvestLights = 3;
 constexpr uint32_t sift_bytes(uint32_t cap) { return 64 * 8 + cap * 4; }
 constexpr uint32_t kSiftBytesPerWave = sift_bytes(kSiftCap);
 constexpr uint32_t kHarvestBytesPerWave = 64 * kHarvestLights * 4;
@@ -597,11 +597,16 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             const uint32_t leaf_first = (uint32_t)__builtin_amdgcn_readlane((int)first_pair, leader);
             const uint32_t leaf_pairs = (uint32_t)__builtin_amdgcn_readlane((int)n_pairs, leader);
             const bool mine = pending && first_pair == leaf_first;
+            // Lanes that take no part get an upper bound of -infinity, which no box interval reaches: the loop then runs the same
+            // arithmetic in every lane, without masking.  HARVEST: a lane whose ray the leaf's box test kept out only collects light
+            // distances, so for it that bound also applies to every pair without a light's primitive.
+            const float upper_all = mine ? h.t : -__builtin_inff();
+            const float upper_inside = mine && !lights_only ? h.t : -__builtin_inff();
             for (uint32_t k = 0; k < leaf_pairs; ++k) {
                 const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
-                const v4f bx = rec[6], bz = rec[7];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, -, -)
-                bool pass = mine && pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, h.t);
-                if (HARVEST && __float_as_uint(bz.z) == 0u) pass = pass && !lights_only;  // bz.z: the pair holds a light's primitive
+                const v4f bx = rec[6], bz = rec[7];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, holds a light's primitive, -)
+                const float upper = HARVEST && __float_as_uint(bz.z) == 0u ? upper_inside : upper_all;  // a wave-uniform choice
+                const bool pass = pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
                 const unsigned long long bal = RRT_BALLOT(pass);
                 if (pass) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));

@@ -13,13 +13,13 @@ img = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
 cnt = torch.zeros(16, dtype=torch.int64, device="cuda")
 sc.render_device(img.data_ptr(), cnt.data_ptr(), 0, samples=spp, background=bg)
 torch.cuda.synchronize()
-out = np.zeros(20, dtype=np.uint64)
+K = 5
+out = np.zeros(3 * K, dtype=np.uint64)
 rrt.lib().rrt_profile_read_pool(ctypes.c_void_p(out.ctypes.data))
-steps, lanes, cyc = out[:6].astype(float), out[6:12].astype(float), out[12:18].astype(float)
+steps, lanes, cyc = out[:K].astype(float), out[K:2 * K].astype(float), out[2 * K:3 * K].astype(float)
 c = cnt.cpu().numpy()
 print("rays %d paths %d" % (c[0], c[1]))
-for i, nm in enumerate(["FREE", "TRACE", "END", "GEN", "LTRI", "LCS"]):
+for i, nm in enumerate(["FREE", "TRACE", "GEN", "LTRI", "LCS"]):
     if steps[i]:
         print("%-6s steps %10d  paths/step %5.1f  cycles %5.1f %%  cycles/step %8.0f" % (nm, steps[i], lanes[i] / steps[i], 100 * cyc[i] / cyc.sum(), cyc[i] / steps[i]))
 print("mean paths per step %.1f; steps per ray %.3f" % (lanes.sum() / steps.sum(), steps.sum() / c[0]))
-print("TRACE: closest hit %.0f cycles/step, density + classification %.0f cycles/step" % (out[18] / steps[1], out[19] / steps[1]))
