@@ -214,10 +214,13 @@ __device__ unsigned long long g_pool_prof[24];  // profiling build only: per kin
 #ifndef RRT_POOL_WAVES
 #define RRT_POOL_WAVES 4
 #endif
-constexpr uint32_t kPool = RRT_POOL;    // paths per wave: 16 x 128 x 4 B = 8 KB; with the query's work area 10 KB: four waves per SIMD
+constexpr uint32_t kPool = RRT_POOL;    // paths per wave: 15 x 128 x 4 B = 7.5 KB; with the query's work area 9.5 KB: four waves per SIMD
 constexpr uint32_t kPoolSiftCap = 192;  // candidate list of the sifting query: flushed early beyond 128 candidates (a step lists about 110)
 constexpr uint32_t kPoolWaves = RRT_POOL_WAVES;  // waves per SIMD the LDS request leaves room for
-enum : uint32_t { P_OX, P_OY, P_OZ, P_DX, P_DY, P_DZ, P_TX, P_TY, P_TZ, P_G0, P_G1, P_PIX, P_META, P_PDF_K, P_T, P_HIT, kPoolFields };
+// P_PDF_T: the cosine lobe's density of a pending bounce on the way from shading to the query, the hit distance on the way back
+// P_HIT: 0 for a miss, else bit 0 = negative determinant, bits 1..25 slot + 1, bits 26..31 the light the light-or-lobe draw chose
+enum : uint32_t { P_OX, P_OY, P_OZ, P_DX, P_DY, P_DZ, P_TX, P_TY, P_TZ, P_G0, P_G1, P_PIX, P_META, P_PDF_T, P_HIT, kPoolFields };
+constexpr uint32_t kPoolMaxLights = 64;
 enum : uint32_t { C_FREE = 0, C_TRACE = 1, C_GEN = 2, C_LTRI = 3, C_LCS = 4, kClasses = 5 };
 // P_META: bits 0..2 class, 3 a diffuse bounce's density is pending, 4 the light-or-lobe draw chose a light, 5..12 depth, 13..31 sample
 constexpr uint32_t kPoolMaxDepth = 255, kPoolMaxSamples = 1u << 19;
@@ -364,11 +367,11 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
                 f3 thr = mk3(__uint_as_float(POOL(P_TX, slot)), __uint_as_float(POOL(P_TY, slot)), __uint_as_float(POOL(P_TZ, slot)));
                 const bool pending = HARVEST && (meta & 8u) != 0u;
                 if (pending) {  // aggregate.rs:79-89 for the previous bounce, now that this ray's light distances are known (thr held the numerator)
-                    const float scatter_pdf = __uint_as_float(POOL(P_PDF_K, slot));
+                    const float scatter_pdf = __uint_as_float(POOL(P_PDF_T, slot));
                     const float pdf_val = mixture_value_harvested(sc, r, harvest) * 0.5f + scatter_pdf * 0.5f;  // pair_value, pdf.rs:117-119
                     thr = thr / pdf_val;
                 }
-                uint32_t towards = 0u;
+                uint32_t towards = 0u, light = 0u;
                 f3 radiance = mk3(0.0f, 0.0f, 0.0f);
                 if (depth < ta.max_depth && hit.slot >= 0) {
                     const uint32_t type = RRT_PLAIN_TYPE(__float_as_uint(sc.c_plain()[2 * hit.slot].w));
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
                             towards = 16u;
                             if (sc.c_lights()[ch.k].kind == RRT_KIND_TRIANGLE) cls = C_LTRI;
                         }
-                        POOL(P_PDF_K, slot) = ch.k;
+                        light = ch.k;
                         POOL(P_G0, slot) = g.s0;
                         POOL(P_G1, slot) = g.s1;
                     } else {
@@ -401,8 +404,8 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
                     if (pending) {
                         POOL(P_TX, slot) = __float_as_uint(thr.x); POOL(P_TY, slot) = __float_as_uint(thr.y); POOL(P_TZ, slot) = __float_as_uint(thr.z);
                     }
-                    POOL(P_T, slot) = __float_as_uint(hit.t);
-                    POOL(P_HIT, slot) = (((uint32_t)hit.slot + 1u) << 1) | (hit.det < 0.0f ? 1u : 0u);
+                    POOL(P_PDF_T, slot) = __float_as_uint(hit.t);
+                    POOL(P_HIT, slot) = (light << 26) | (((uint32_t)hit.slot + 1u) << 1) | (hit.det < 0.0f ? 1u : 0u);
                     POOL(P_META, slot) = (meta & ~(7u | 8u | 16u)) | cls | towards;
                 }
             }
@@ -421,11 +424,11 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
             f3 thr = mk3(__uint_as_float(POOL(P_TX, slot)), __uint_as_float(POOL(P_TY, slot)), __uint_as_float(POOL(P_TZ, slot)));
             const uint32_t hw = POOL(P_HIT, slot);
             Hit hit;
-            hit.slot = (int)(hw >> 1) - 1;
-            hit.t = __uint_as_float(POOL(P_T, slot));
+            hit.slot = (int)((hw >> 1) & 0x01ffffffu) - 1;
+            hit.t = __uint_as_float(POOL(P_PDF_T, slot));
             hit.u = hit.v = 0.0f;
             hit.det = (hw & 1u) ? -1.0f : 1.0f;  // only the sign is used (by the hit properties)
-            const LightChoice chosen = {(meta & 16u) != 0u, POOL(P_PDF_K, slot)};
+            const LightChoice chosen = {(meta & 16u) != 0u, hw >> 26};
             PendingPdf pend;
             pend.active = false;
             pend.numerator = mk3(0.0f, 0.0f, 0.0f);
@@ -446,7 +449,7 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
                 POOL(P_DX, slot) = __float_as_uint(r.d.x); POOL(P_DY, slot) = __float_as_uint(r.d.y); POOL(P_DZ, slot) = __float_as_uint(r.d.z);
                 POOL(P_TX, slot) = __float_as_uint(keep.x); POOL(P_TY, slot) = __float_as_uint(keep.y); POOL(P_TZ, slot) = __float_as_uint(keep.z);
                 POOL(P_G0, slot) = g.s0; POOL(P_G1, slot) = g.s1;
-                if (pending) POOL(P_PDF_K, slot) = __float_as_uint(pend.scatter_pdf);
+                if (pending) POOL(P_PDF_T, slot) = __float_as_uint(pend.scatter_pdf);
                 POOL(P_META, slot) = (meta & ~(7u | 8u | 16u | (255u << 5))) | C_TRACE | (pending ? 8u : 0u) | ((depth + 1u) << 5);
             }
         }
@@ -1624,7 +1627,8 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
         const dim3 grid((unsigned)items);
         float* const pass_slab = static_staging ? slab : s->slab;
         // shallow trees, plain feature set: the pooled schedule (k_trace_pool) - a persistent grid that hands the items out itself
-        if (s->pooling && !s->deep && (need & ~kPlain) == 0 && ta.max_depth <= kPoolMaxDepth && ta.n_samples <= kPoolMaxSamples) {
+        if (s->pooling && !s->deep && (need & ~kPlain) == 0 && ta.max_depth <= kPoolMaxDepth && ta.n_samples <= kPoolMaxSamples &&
+            s->d.n_lights <= kPoolMaxLights) {
             ta.n_items = (uint32_t)items;
             const dim3 pgrid((unsigned)(items < s->wave_places ? items : s->wave_places));
             if (s->harvest) ta.stack_depth = 0;  // a single leaf: the walk never pushes

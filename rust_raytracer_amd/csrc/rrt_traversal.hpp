@@ -532,7 +532,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long* best = (unsigned long long*)area;
     uint32_t* items = (uint32_t*)(area + 64 * 8);
-    const f3 inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    const f3 inv = mk3(exact_rcp(r.d.x), exact_rcp(r.d.y), exact_rcp(r.d.z));  // = 1.0f / r.d, bit for bit (see exact_rcp)
     // for the pair boxes: plane * finv + noi (see pair_box_overlap); an axis whose product origin * inv is not finite (zero or
     // denormal direction component) gets NaN, which the interval test ignores: that axis then constrains nothing
     f3 finv = inv, noi = mk3(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));

@@ -420,3 +420,53 @@ def test_resolve_rgb8(gpu):
     img[0, 0] = [np.nan, -1.0, 1e9]
     img[1, 1] = [0.0, 16.0, 15.999]
     assert np.array_equal(rrt.resolve_rgb8(img, 16), orc.resolve_rgb8(img, 16))
+
+
+@pytest.mark.parametrize("name,W,H,spp", [("Cornell_Box_With_Sphere.json", 200, 136, 20), ("Cornell_Box.json", 333, 222, 9), ("Cornell_Box.json", 64, 64, 300)])
+def test_pooled_and_lockstep_schedules_give_the_oracle_frame(gpu, name, W, H, spp):
+    """Plain shallow scenes are traced by k_trace_pool (128 paths of a wave pooled in LDS, one kind of work per step) unless
+    rrt_scene_set_pooling(0) asks for k_trace (one path per lane): both must give the oracle's frame bit for bit, in both box-test
+    modes, over ragged frames (partial 8x8 and 32x32 tiles), across item boundaries (more samples than a 64-sample chunk) and
+    with interleaved tiles."""
+    o, g = both(name, resolution_x=W, resolution_y=H, samples=spp)
+    ref, st_ref = o.render(W, H, spp, seed=12, threads=min(16, len(__import__("os").sched_getaffinity(0))))
+    for pooled in (True, False):
+        g.set_pooling(pooled)
+        for mode in (rrt.AABB_TIGHT, rrt.AABB_REFERENCE):
+            img, st = g.render(seed=12, aabb_mode=mode)
+            same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+            assert same.all(), "%d of %d values differ (pooled %s, mode %d)" % ((~same).sum(), same.size, pooled, mode)
+            assert st["rays"] == int(st_ref[0]) and st["paths"] == W * H * spp
+        tiled = np.zeros_like(ref)
+        for k in range(3):
+            g.render(seed=12, tile_count=3, tile_index=k, out=tiled)
+        assert ((bits(tiled) == bits(ref)) | (np.isnan(tiled) & np.isnan(ref))).all()
+    g.set_pooling(True)
+    g.set_staging_limit(W * H * 12 * 7)  # seven samples per pass: many short launches of the persistent grid
+    img, st = g.render(seed=12)
+    assert ((bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))).all() and st["rays"] == int(st_ref[0])
+
+
+def test_pooled_schedule_with_a_depth_limit_and_many_lights(gpu):
+    """max_depth below the default (paths cut off by the limit see the background), and a scene of more lights than the
+    harvesting query handles (the pooled kernel's plain, non-harvesting variant; light-or-lobe draws made in the trace step)."""
+    o, g = both("Cornell_Box_With_Sphere.json", resolution_x=72, resolution_y=56, samples=10)
+    for depth in (0, 1, 3):
+        ref, st_ref = o.render(72, 56, 10, seed=2, bg=rrt.BG_SKY, max_depth=depth)
+        for pooled in (True, False):
+            g.set_pooling(pooled)
+            img, st = g.render(seed=2, background=rrt.BG_SKY, max_depth=depth)
+            same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+            assert same.all() and st["rays"] == int(st_ref[0]), (depth, pooled)
+    d = synth.slats_desc(n=6, aggregate=1, spheres=2)
+    d["shapes"] += [dict(d["shapes"][-1], transform=([0.3 * i, 0.0, 0.1 * i], [0.0, 0.0, 0.0], [0.5, 1.0, 0.5])) for i in range(1, 4)]  # four light quads
+    o2 = orc.OracleScene(d)
+    hs = synth.host_scene(d)
+    assert hs.desc.n_lights > 3  # the light quads plus every Metal and Dielectric shape (material.rs:162, 209)
+    g2 = rrt.Scene(hs)
+    ref, st_ref = o2.render(40, 32, 6, seed=5, bg=rrt.BG_SKY)
+    for pooled in (True, False):
+        g2.set_pooling(pooled)
+        img, st = g2.render(samples=6, seed=5, background=rrt.BG_SKY)
+        same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all() and st["rays"] == int(st_ref[0]), pooled
