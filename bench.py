@@ -240,11 +240,14 @@ def main():
                 achieved = rays_per_launch * per_ray / k_s / 1e9
                 roofline.update({"achieved": achieved, "frac": achieved / VALU_PEAK_GINSTR, "valu_issue_frac": achieved / VALU_PEAK_GINSTR,
                                  "valu_wave_instr_per_ray": per_ray, "lane_utilisation": pmc.get("lane_utilisation"),
-                                 "salu_instr_per_ray": pmc.get("salu_instr_per_ray"), "valu_busy_frac": pmc.get("valu_busy_frac")})
+                                 "salu_instr_per_ray": pmc.get("salu_instr_per_ray"), "valu_busy_frac": pmc.get("valu_busy_frac"),
+                                 "valu_cycles_per_instruction": pmc.get("valu_cycles_per_instruction")})
             else:
                 roofline.update({"achieved": None, "frac": None})
-            roofline["limiter"] = ("vector ALU issue: SQ_ACTIVE_INST_VALU covers the whole launch; the 192 B/ray figure (nominal_hbm_*) is what a "
-                                   "queue-based tracer would move, this kernel moves about 3.4 B/ray (traffic)")
+            roofline["limiter"] = ("vector ALU: `peak` is one wave instruction per 2 cycles per SIMD (plain f32 multiply-add), but this kernel's mix "
+                                   "(packed f32, scalar operands, compares, selects, min/max, reciprocal, square root) costs valu_cycles_per_instruction on "
+                                   "average, and with that mix the ALU is busy valu_busy_frac of the launch; the 192 B/ray figure (nominal_hbm_*) is what a "
+                                   "queue-based tracer would move, this kernel moves about 5 B/ray (traffic)")
         out = {
             "metric": "Mrays/sec (whole node) + time-to-image, Cornell box 1024^2 @1024 spp",
             "value": rays_total / elapsed / 1e6,

@@ -185,7 +185,13 @@ typedef struct rrt_scene rrt_scene; /* device-resident scene */
 typedef struct rrt_host_scene rrt_host_scene; /* host-side builder / loader */
 
 enum { RRT_BG_BLACK = 0 /* main.rs:268-270 */, RRT_BG_SKY = 1 /* main.rs:259-267 */ };
-enum { RRT_AABB_TIGHT = 0 /* complete slab test, superset-safe */, RRT_AABB_REFERENCE = 1 /* aggregate.rs:471-503 verbatim */ };
+/* Bounding-box test of the traversal.  All three return the same hits and frames; they differ in what is allowed to cull.
+ *   TIGHT       the reference's test on its own boxes AND the padded boxes the primitives really occupy (nodes), padded pair boxes
+ *               before the exact primitive tests (small scenes): the fast one
+ *   REFERENCE   nodes by aggregate.rs:471-503 verbatim alone (the padded pair boxes of small scenes still apply)
+ *   EXHAUSTIVE  nodes by the reference's test alone and every primitive of a visited leaf through the exact test: no padded box
+ *               decides anything, so it is the reference's result by construction - the yardstick for the other two */
+enum { RRT_AABB_TIGHT = 0, RRT_AABB_REFERENCE = 1, RRT_AABB_EXHAUSTIVE = 2 };
 
 typedef struct rrt_render_params {
     uint32_t width, height;   /* 0 = the scene's Logistics */

@@ -40,6 +40,7 @@ pub const RRT_BG_BLACK: u32 = 0; // main.rs:268-270
 pub const RRT_BG_SKY: u32 = 1; // main.rs:259-267 (commented out in the reference)
 pub const RRT_AABB_TIGHT: u32 = 0;
 pub const RRT_AABB_REFERENCE: u32 = 1; // aggregate.rs:471-503 verbatim
+pub const RRT_AABB_EXHAUSTIVE: u32 = 2; // no padded box culls anything
 pub const RRT_RENDER_ACCUMULATE: u32 = 1;
 pub const RRT_AGGREGATE_LIST: c_int = 0; // "Aggregate": "List", scene.rs:610
 pub const RRT_AGGREGATE_BVH: c_int = 1; // aggregate.rs:187-322 on the host

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RRT_LIB") or os.path.join(_HERE, "librrt_hip.so")
 
 BG_BLACK, BG_SKY = 0, 1
-AABB_TIGHT, AABB_REFERENCE = 0, 1
+AABB_TIGHT, AABB_REFERENCE, AABB_EXHAUSTIVE = 0, 1, 2
 RENDER_ACCUMULATE = 1
 SHARD_SAMPLES, SHARD_TILES = 0, 1
 KIND_TRIANGLE, KIND_SPHERE, KIND_MEDIUM = 0, 1, 2

@@ -8,7 +8,7 @@
 // -t is accepted and validated like the reference's (a positive integer, default 2) but selects nothing here: the
 // samples are traced by the GPU, not by host threads.
 // Extensions (not in the reference): --background black|sky (main.rs:259-270 keeps the sky gradient commented out),
-// --seed N, --aabb tight|reference, --samples N / --width N / --height N overriding the scene's Logistics,
+// --seed N, --aabb tight|reference|exhaustive, --samples N / --width N / --height N overriding the scene's Logistics,
 // --gpus N (the reference's N host threads draining one sample queue, main.rs:136-165, become N GPUs each tracing a share of the
 // frame: rrt_render_multi) with --shard samples|tiles, and --stats (the reference's single "Took N seconds" split by phase).
 #include <fcntl.h>
@@ -66,7 +66,7 @@ struct Progress {
                  "    -t, --thread-count <THREAD_COUNT>    Number of threads to use while tracing\n"
                  "        --background <black|sky>         Colour of rays that leave the scene (default black)\n"
                  "        --seed <N>                       Seed of the per-sample random streams (default 0)\n"
-                 "        --aabb <tight|reference>         Bounding-box test of the BVH walk (default tight)\n"
+                 "        --aabb <tight|reference|exhaustive>  Bounding-box test of the BVH walk (default tight)\n"
                  "        --tree <host|gpu|clean>          Where and how a \"BVH\" aggregate is built: the reference's tree on the host\n"
                  "                                         (default) or on the GPU, or the clean tree with the List aggregate's results\n"
                  "        --samples <N> --width <N> --height <N>   Override the scene's Logistics\n"
@@ -118,7 +118,8 @@ int main(int argc, char** argv) {
             std::string v = value("--aabb");
             if (v == "tight") aabb = RRT_AABB_TIGHT;
             else if (v == "reference") aabb = RRT_AABB_REFERENCE;
-            else usage("--aabb takes tight or reference");
+            else if (v == "exhaustive") aabb = RRT_AABB_EXHAUSTIVE;
+            else usage("--aabb takes tight, reference or exhaustive");
         } else if (a == "--tree") {
             std::string v = value("--tree");
             if (v == "host") tree = RRT_AGGREGATE_BVH;

@@ -1461,7 +1461,7 @@ static int check_device(const rrt_scene* s) {
 int rrt_intersect_batch_device(rrt_scene* s, const float* d_o, const float* d_d, size_t n, float t_min, float t_max, uint32_t aabb_mode,
                                uint32_t seed, int32_t* d_prim, float* d_t, void* stream) {
     if (!s || (n && (!d_o || !d_d || !d_prim || !d_t))) return rrt_set_error(RRT_ERR_INVALID, "rrt_intersect_batch: NULL argument");
-    if (aabb_mode > RRT_AABB_REFERENCE) return rrt_set_error(RRT_ERR_INVALID, "rrt_intersect_batch: unknown aabb_mode");
+    if (aabb_mode > RRT_AABB_EXHAUSTIVE) return rrt_set_error(RRT_ERR_INVALID, "rrt_intersect_batch: unknown aabb_mode");
     if (int rc = check_device(s)) return rc;
     if (n == 0) return RRT_OK;
     if (n > (size_t)0x7fffffff * kBlock) return rrt_set_error(RRT_ERR_LIMIT, "rrt_intersect_batch: too many rays for one launch");
@@ -1475,13 +1475,15 @@ int rrt_intersect_batch_device(rrt_scene* s, const float* d_o, const float* d_d,
         const dim3 grid((unsigned)((n + run - 1) / run));
 #define RRT_LAUNCH_BATCH(MODE) hipLaunchKernelGGL((k_intersect_stream<MODE>), grid, dim3(kTraceBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, run, 24u, d_prim, d_t)
         if (s->clean) RRT_LAUNCH_BATCH(kAabbClean);
-        else if (aabb_mode == RRT_AABB_REFERENCE) RRT_LAUNCH_BATCH(RRT_AABB_REFERENCE);
+        else if (aabb_mode != RRT_AABB_TIGHT) RRT_LAUNCH_BATCH(RRT_AABB_REFERENCE);  // deep trees: the reference's test alone IS exhaustive (leaves are tested whole)
         else RRT_LAUNCH_BATCH(RRT_AABB_TIGHT);
 #undef RRT_LAUNCH_BATCH
     } else {
         const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
         const size_t lds = (size_t)kBlock * s->stack_depth * sizeof(uint32_t) + (size_t)(kBlock / 64) * kSiftBytesPerWave;
-        if (aabb_mode == RRT_AABB_REFERENCE)
+        if (aabb_mode == RRT_AABB_EXHAUSTIVE)
+            hipLaunchKernelGGL((k_intersect<kAabbExhaustive>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
+        else if (aabb_mode == RRT_AABB_REFERENCE)
             hipLaunchKernelGGL((k_intersect<RRT_AABB_REFERENCE>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
         else
             hipLaunchKernelGGL((k_intersect<RRT_AABB_TIGHT>), grid, dim3(kBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, s->stack_depth, d_prim, d_t);
@@ -1526,7 +1528,7 @@ struct RenderPlan {
 static int plan_render(rrt_scene* s, const rrt_render_params* p, RenderPlan* plan) {
     if (!s || !p) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: NULL argument");
     if (int rc = check_device(s)) return rc;
-    if (p->aabb_mode > RRT_AABB_REFERENCE) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: unknown aabb_mode");
+    if (p->aabb_mode > RRT_AABB_EXHAUSTIVE) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: unknown aabb_mode");
     if (p->background > RRT_BG_SKY) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: unknown background");
     if (p->flags & ~(uint32_t)RRT_RENDER_ACCUMULATE) return rrt_set_error(RRT_ERR_INVALID, "rrt_render: unknown flags");
     TraceArgs& ta = plan->ta;
@@ -1627,8 +1629,11 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
         const dim3 grid((unsigned)items);
         float* const pass_slab = static_staging ? slab : s->slab;
         // shallow trees, plain feature set: the pooled schedule (k_trace_pool) - a persistent grid that hands the items out itself
-        if (s->pooling && !s->deep && (need & ~kPlain) == 0 && ta.max_depth <= kPoolMaxDepth && ta.n_samples <= kPoolMaxSamples &&
-            s->d.n_lights <= kPoolMaxLights) {
+        if (p->aabb_mode == RRT_AABB_EXHAUSTIVE && !s->deep) {
+            // the yardstick mode on a shallow tree: one kernel variant (every feature, one path per lane); speed is not its point
+            hipLaunchKernelGGL((k_trace<kAabbExhaustive, F_ALL>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt);
+        } else if (s->pooling && !s->deep && (need & ~kPlain) == 0 && ta.max_depth <= kPoolMaxDepth && ta.n_samples <= kPoolMaxSamples &&
+                   s->d.n_lights <= kPoolMaxLights) {
             ta.n_items = (uint32_t)items;
             const dim3 pgrid((unsigned)(items < s->wave_places ? items : s->wave_places));
             if (s->harvest) ta.stack_depth = 0;  // a single leaf: the walk never pushes
@@ -1661,7 +1666,7 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
         if (s->clean) {
             if ((need & ~kPlain) == 0) RRT_LAUNCH_STREAM(kAabbClean, kPlain);
             else RRT_LAUNCH_STREAM(kAabbClean, F_ALL);
-        } else if (p->aabb_mode == RRT_AABB_REFERENCE) RRT_PICK(RRT_AABB_REFERENCE);
+        } else if (p->aabb_mode != RRT_AABB_TIGHT) RRT_PICK(RRT_AABB_REFERENCE);
         else RRT_PICK(RRT_AABB_TIGHT);
         }
 #undef RRT_PICK

@@ -194,6 +194,10 @@ RRT_DEV bool pair_box_overlap(v2f_ x, v2f_ y, v2f_ z, f3 inv, f3 noi, float t_mi
 // tested with the ordinary interval test on their primitive boxes alone, and equal distances go to the shape that comes
 // first in SCENE order - together exactly what the reference's List aggregate returns (aggregate.rs:142-165).
 constexpr int kAabbClean = 2;
+// Fourth traversal mode (RRT_AABB_EXHAUSTIVE): nodes by the reference's test alone, and EVERY primitive of a visited leaf gets the
+// exact test - no padded box decides anything, so the result is the reference's by construction.  The yardstick the padded-box
+// shortcuts (primitive boxes of nodes, pair boxes of the sifting query) are held against.
+constexpr int kAabbExhaustive = 3;
 constexpr uint32_t kLinkLeaf = 0x80000000u;  // clean trees: a child link that names a leaf's pair records directly
 constexpr uint32_t kLinkNone = 0xffffffffu;  // clean trees: an unused child place of a four-wide node
 

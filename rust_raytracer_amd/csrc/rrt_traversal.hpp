@@ -606,7 +606,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                 const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
                 const v4f bx = rec[6], bz = rec[7];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, holds a light's primitive, -)
                 const float upper = HARVEST && __float_as_uint(bz.z) == 0u ? upper_inside : upper_all;  // a wave-uniform choice
-                const bool pass = pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
+                const bool pass = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
                 const unsigned long long bal = RRT_BALLOT(pass);
                 if (pass) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));

@@ -66,3 +66,56 @@ def ray_batch(oracle_scene, W, H, n_random=4096, seed=0, max_corners=4000):
     ro = np.ascontiguousarray(np.concatenate(origins), dtype=np.float32)
     rd = np.ascontiguousarray(np.concatenate(dirs), dtype=np.float32)
     return ro, rd
+
+
+GRAZER_TILTS = (0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 0.1, 1.0)
+
+
+def triangle_outline_grazers(slots, extent, seed=0, max_triangles=48, per_edge=6, tilts=GRAZER_TILTS):
+    """Rays built to fall between the exact triangle test and a padded box around the triangle: each passes a point on (or a
+    few 1e-7..1e-4 of the scene's extent beside) a triangle's outline - vertices included - in a direction that leaves the
+    triangle's plane by an angle between 0 and 1 rad, from either side.  Near the plane the exact test's own rounding accepts
+    points slightly outside the triangle, which is where a box shortcut could lose a hit the exact test alone would find.
+
+    slots: the structured array HostScene.slots() returns; extent: the scene's largest coordinate.
+    Returns (origins, directions, slot of the triangle aimed at, angle off its plane in rad) per ray."""
+    rng = np.random.default_rng(seed)
+    tri = np.nonzero((slots["info"] >> 30) == 0)[0]
+    if len(tri) > max_triangles:
+        tri = np.sort(rng.choice(tri, max_triangles, replace=False))
+    offs = np.array([0.0, 1e-7, -1e-7, 1e-6, -1e-6, 3e-6, -3e-6, 1e-5, -1e-5, 3e-5, -3e-5, 1e-4], dtype=np.float64) * extent
+    tilts = np.asarray(tilts, dtype=np.float64)
+    origins, dirs, which, angle = [], [], [], []
+    for s in tri:
+        v0 = slots["v0"][s].astype(np.float64)
+        e1 = slots["e1"][s].astype(np.float64)
+        e2 = slots["e2"][s].astype(np.float64)
+        n = np.cross(e1, e2)
+        if not np.linalg.norm(n) > 0.0:
+            continue
+        n /= np.linalg.norm(n)
+        centre = v0 + (e1 + e2) / 3.0
+        for start, along in ((v0, e1), (v0, e2), (v0 + e1, e2 - e1)):
+            a = np.concatenate([[0.0, 1.0], rng.uniform(0.0, 1.0, per_edge - 2)])
+            unit = along / np.linalg.norm(along)
+            out = np.cross(unit, n)
+            if np.dot(out, start + 0.5 * along - centre) < 0.0:
+                out = -out
+            pts = start[None, :] + a[:, None] * along[None, :]
+            A, D, T = np.meshgrid(np.arange(len(a)), np.arange(len(offs)), np.arange(len(tilts)), indexing="ij")
+            A, D, T = A.ravel(), D.ravel(), T.ravel()
+            k = len(A)
+            target = pts[A] + offs[D][:, None] * out[None, :]
+            phi = rng.uniform(0.0, 2.0 * np.pi, k)
+            phi = np.where(rng.uniform(0.0, 1.0, k) < 0.3, rng.choice([0.0, np.pi], k), phi)  # along the edge: past the triangle, never across it
+            w = np.cos(phi)[:, None] * unit[None, :] + np.sin(phi)[:, None] * out[None, :]  # in the plane
+            side = rng.choice([-1.0, 1.0], k)
+            d = np.cos(tilts[T])[:, None] * w + (side * np.sin(tilts[T]))[:, None] * n[None, :]
+            d *= rng.choice([1.0, 0.37, 2.9], k)[:, None]  # the reference's rays are not all unit length
+            o = target - rng.uniform(0.01, 1.0, k)[:, None] * extent * d
+            origins.append(o)
+            dirs.append(d)
+            which.append(np.full(k, s, dtype=np.int32))
+            angle.append(tilts[T])
+    return (np.ascontiguousarray(np.concatenate(origins), dtype=np.float32), np.ascontiguousarray(np.concatenate(dirs), dtype=np.float32),
+            np.concatenate(which), np.concatenate(angle))

@@ -1,0 +1,139 @@
+"""The padded-box shortcuts of the traversal against the mode that has none.
+
+RRT_AABB_TIGHT culls nodes by the padded boxes their primitives occupy, and on small scenes both TIGHT and REFERENCE sift the
+pairs of a leaf by padded pair boxes before the exact tests.  RRT_AABB_EXHAUSTIVE uses the reference's node test alone and
+sends every primitive of a visited leaf through the exact test, so it equals the reference by construction.  The rays here are
+built for the one place where a shortcut could lose a hit: along triangle outlines, at grazing angles, where Moeller-Trumbore's
+own rounding accepts points slightly OUTSIDE the triangle (aggregate.rs:324-401 tests every shape of a leaf, shape.rs:335-372).
+All three modes must return the oracle's answer bit for bit."""
+import numpy as np
+import pytest
+
+import orc
+import rays as raygen
+import rust_raytracer_amd as rrt
+import synth
+
+pytestmark = pytest.mark.gpu
+
+MODES = (rrt.AABB_TIGHT, rrt.AABB_REFERENCE, rrt.AABB_EXHAUSTIVE)
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def scene_pair(case):
+    if case.endswith(".json"):
+        o = orc.OracleScene.from_file(orc.asset(case), {"resolution_x": 32, "resolution_y": 32})
+        g = rrt.Scene.load(orc.asset(case), width=32, height=32)
+        return o, g
+    d = {"slats": lambda: synth.slats_desc(n=24, aggregate=1), "slats_list": lambda: synth.slats_desc(n=24, aggregate=0),
+         "soup": lambda: synth.soup_desc(n=400), "terrain": lambda: synth.terrain_desc(12, amplitude=0.02)}[case]()
+    return orc.OracleScene(d), rrt.Scene(synth.host_scene(d))
+
+
+def outside_in_exact_arithmetic(slots, ro, rd, which, prim_slot_hit):
+    """Of the rays whose accepted hit is the triangle they were aimed at: how many meet that triangle's plane OUTSIDE the
+    triangle when the intersection is worked out in float64, and how far outside (in-plane distance) at most."""
+    s = which[prim_slot_hit]
+    v0 = slots["v0"][s].astype(np.float64)
+    e1 = slots["e1"][s].astype(np.float64)
+    e2 = slots["e2"][s].astype(np.float64)
+    o = ro[prim_slot_hit].astype(np.float64)
+    d = rd[prim_slot_hit].astype(np.float64)
+    p = np.cross(d, e2)
+    det = np.einsum("ij,ij->i", e1, p)
+    ok = det != 0.0
+    tv = o - v0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        u = np.einsum("ij,ij->i", tv, p) / det
+        q = np.cross(tv, e1)
+        v = np.einsum("ij,ij->i", d, q) / det
+        out = ok & ((u < 0.0) | (v < 0.0) | (u + v > 1.0))
+        excess = np.maximum(np.maximum(-u, -v), u + v - 1.0)  # in barycentric units
+    scale = np.maximum(np.linalg.norm(e1, axis=1), np.linalg.norm(e2, axis=1))
+    return int(out.sum()), float((excess * scale)[out].max()) if out.any() else 0.0
+
+
+def misses_grown_box(slots, s, o, d, pad):
+    """float64 slab test: True where the ray o + t d (t >= 0) does not touch the box of triangle slot s grown by pad."""
+    v0 = slots["v0"][s].astype(np.float64)
+    v1 = v0 + slots["e1"][s].astype(np.float64)
+    v2 = v0 + slots["e2"][s].astype(np.float64)
+    lo = np.minimum(np.minimum(v0, v1), v2) - pad
+    hi = np.maximum(np.maximum(v0, v1), v2) + pad
+    o = o.astype(np.float64)
+    d = d.astype(np.float64)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t0 = (lo - o) / d
+        t1 = (hi - o) / d
+    near = np.where(d != 0.0, np.minimum(t0, t1), np.where((o >= lo) & (o <= hi), -np.inf, np.inf))
+    far = np.where(d != 0.0, np.maximum(t0, t1), np.where((o >= lo) & (o <= hi), np.inf, -np.inf))
+    return ~(np.maximum(near.max(axis=1), 0.0) <= far.min(axis=1))
+
+
+CASES = ["Cornell_Box_With_Sphere.json", "Cornell_Box.json", "Example_Spec.json", "slats", "slats_list", "soup", "terrain"]
+SAFE_ANGLE = 0.01  # rad off the triangle's plane from which the padding covers the exact test's rounding (see the module text)
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_rays_along_triangle_outlines_at_grazing_angles(gpu, case):
+    """What the three modes return for rays along triangle outlines:
+    * EXHAUSTIVE equals the oracle on every ray, whatever the angle;
+    * TIGHT and REFERENCE equal it on every ray that leaves the plane of the triangle it was aimed at by 0.01 rad or more;
+    * closer to the plane the reference's arithmetic reports "hits" on triangles the ray passes BESIDE (the rounding error of
+      u, v grows as 1/angle and outruns any fixed padding); the shortcuts drop exactly those: every ray they answer differently
+      is one that, in float64, does not touch the reported triangle's box grown by the padding (in a tree: nearly every
+      one - a dropped artefact can also change what the reference's walk prunes afterwards), and they are few."""
+    o, g = scene_pair(case)
+    slots = g.host.slots()
+    bb = o.shape_bboxes()
+    extent = float(np.abs(bb[np.isfinite(bb).all(axis=1)]).max())
+    pad = 1e-5 * extent
+    ro, rd, which, angle = raygen.triangle_outline_grazers(slots, extent, seed=5)
+    assert len(ro) > 20000
+    slot_of_prim = np.full(int(slots["prim"].max()) + 1, -1, dtype=np.int64)
+    slot_of_prim[slots["prim"]] = np.arange(len(slots))
+    for t_min in (0.001, 0.0):
+        p_ref, t_ref = o.intersect(ro, rd, t_min=t_min)
+        assert (p_ref >= 0).sum() > len(ro) // 4
+        for mode in MODES:
+            p, t = g.hit(ro, rd, t_min=t_min, aabb_mode=mode)
+            bad = (p != p_ref) | (bits(t) != bits(t_ref))
+            if mode == rrt.AABB_EXHAUSTIVE:
+                assert not bad.any(), "exhaustive mode, t_min %g: %d of %d rays differ from the oracle" % (t_min, bad.sum(), len(ro))
+                continue
+            steep = angle >= SAFE_ANGLE
+            assert not (bad & steep).any(), "mode %d, t_min %g: %d rays at %g rad or more off the plane differ from the oracle" % (
+                mode, t_min, (bad & steep).sum(), SAFE_ANGLE)
+            i = np.nonzero(bad)[0]
+            print("%s mode %d t_min %g: %d of %d rays differ, all closer than %g rad to a triangle's plane" % (case, mode, t_min, len(i), len(ro), SAFE_ANGLE))
+            assert len(i) <= len(ro) // 500
+            # each of them: the oracle reports a triangle whose grown box the ray does not touch
+            assert (p_ref[i] >= 0).all()
+            s = slot_of_prim[p_ref[i]]
+            assert ((slots["info"][s] >> 30) == 0).all()
+            beside = misses_grown_box(slots, s, ro[i], rd[i], 0.99 * pad)
+            if g.host.desc.n_nodes <= 3:
+                assert beside.all()
+            else:  # in a tree, a dropped rounding artefact can also change which subtrees the reference's walk prunes afterwards
+                assert beside.sum() * 4 >= len(i) * 3
+    # the batch must contain what it was built for: hits the rounding of the exact test lets in from outside the triangle
+    prim_of_slot = slots["prim"].astype(np.int64)
+    aimed_hit = (p_ref >= 0) & (prim_of_slot[which] == p_ref)
+    n_out, far = outside_in_exact_arithmetic(slots, ro, rd, which, aimed_hit)
+    print("%s: %d rays, %d hit the triangle aimed at, %d of them from outside it in float64" % (case, len(ro), aimed_hit.sum(), n_out))
+    assert n_out > 0
+
+
+@pytest.mark.parametrize("case", ["Cornell_Box_With_Sphere.json", "Materials.json", "Example_Spec.json", "slats"])
+def test_exhaustive_mode_renders_the_oracle_frame(gpu, case):
+    o, g = scene_pair(case)
+    W, H, spp = (32, 32, 8)
+    ref, st_ref = o.render(W, H, spp, seed=3, bg=rrt.BG_SKY)
+    for mode in MODES:
+        img, st = g.render(width=W, height=H, samples=spp, seed=3, background=rrt.BG_SKY, aabb_mode=mode)
+        same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), "%d of %d values differ (mode %d)" % ((~same).sum(), same.size, mode)
+        assert st["rays"] == int(st_ref[0])
