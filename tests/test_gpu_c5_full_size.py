@@ -68,11 +68,11 @@ def _run(note):
     # (c) a 32 x 32 frame at 1 spp: radiance sums and ray count
     ref = np.zeros((H, W, 3), dtype=np.float32)
     rays_ref = 0
-    for y0 in range(0, H, 8):
-        part, st_part = o.render(W, H, 1, seed=3, threads=16, rows=(y0, y0 + 8))
-        ref[y0:y0 + 8] = part[y0:y0 + 8]
+    for y0 in range(0, H, 4):
+        part, st_part = o.render(W, H, 1, seed=3, threads=16, rows=(y0, y0 + 4))
+        ref[y0:y0 + 4] = part[y0:y0 + 4]
         rays_ref += int(st_part[0])
-        note("oracle: rows %d..%d of the %d x %d @ 1 frame" % (y0, y0 + 8, W, H))
+        note("oracle: rows %d..%d of the %d x %d @ 1 frame" % (y0, y0 + 4, W, H))
     img, st = g.render(seed=3)
     same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
     assert same.all(), "%d of %d values differ" % ((~same).sum(), same.size)
@@ -100,10 +100,10 @@ def _run(note):
     p, t = gcl.hit(lo, ld)
     assert np.array_equal(p, p_list), "primitive ids differ: %d rays" % (p != p_list).sum()
     assert np.array_equal(bits(t), bits(t_list))
-    # the clean tree's frame: same ray count and sums as the List aggregate's on a 12 x 12 frame
-    ref, st_ref = o_list.render(12, 12, 1, seed=4, threads=16)
-    note("oracle: 12 x 12 @ 1 frame with the List aggregate")
-    img, st = gcl.render(width=12, height=12, samples=1, seed=4)
+    # the clean tree's frame: same ray count and sums as the List aggregate's on an 8 x 8 frame
+    ref, st_ref = o_list.render(8, 8, 1, seed=4, threads=16)
+    note("oracle: 8 x 8 @ 1 frame with the List aggregate")
+    img, st = gcl.render(width=8, height=8, samples=1, seed=4)
     same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
     assert same.all() and st["rays"] == int(st_ref[0])
     # and a full-size sanity pass of the clean tree: 4.2 M camera-like rays, every hit distance finite, every id a valid shape

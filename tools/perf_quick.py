@@ -23,7 +23,7 @@ if os.environ.get("RRT_POOLING") == "0":
 img = torch.zeros((H, W, 3), dtype=torch.float32, device="cuda")
 cnt = torch.zeros(2, dtype=torch.int64, device="cuda")
 st = torch.cuda.current_stream()
-for mode in (rrt.AABB_TIGHT,):
+for mode in [int(m) for m in os.environ.get("RRT_MODES", "0").split(",")]:  # 0 tight, 1 reference, 2 exhaustive
     sc.render_device(img.data_ptr(), cnt.data_ptr(), st.cuda_stream, background=bg, aabb_mode=mode)
     torch.cuda.synchronize()
     ts = []
