@@ -14,26 +14,11 @@
 
 #include "rrt_device.hpp"
 #include "rrt_error.hpp"
+#include "rrt_launch.hpp"
 
 using namespace rrt;
 
 namespace {
-
-constexpr int kBlock = 256;              // k_intersect: 4 waves per block
-constexpr int kTraceBlock = 64;          // k_trace: one wave per block, the unit the hardware dispatcher balances
-#ifndef RRT_CHUNK
-#define RRT_CHUNK 64
-#endif
-constexpr uint32_t kChunk = RRT_CHUNK;   // samples of each pixel handled by one wave item
-constexpr int kWalkSteps = 4;            // k_trace_stream: node steps per turn of the wave's loop (1 / 2 / 3 / 4 / 6 measured on a 500 000-triangle
-                                         // mesh: 141.6 / 134.6 / 131.7 / 132.9 / 129.7 ms; 10 M triangles at 4K: 603 / 579 / 566 / 560 / 565 ms)
-constexpr uint32_t kMaxStackDepth = 64;  // traversal stack: entries per lane
-constexpr uint32_t kLdsStackEntries = 32;  // k_trace_stream keeps this many of them in LDS (10 KB per wave with the cooperative area: 16 waves
-                                           // per compute unit), the rest in private memory
-constexpr uint32_t kDeepTreeNodes = 16;  // trees with more nodes than this take the cooperative-leaf walk
-constexpr size_t kMaxTimedPasses = 4096;   // render passes whose events a scene handle keeps between two rrt_scene_kernel_times calls
-constexpr size_t kSlabCapBytes = 16ull << 30;  // default budget of the per-sample radiance staging buffer (per scene handle, per GPU):
-                                               // sized for 288 GB of HBM, so that a 1024x1024 frame at 1024 spp is a single pass
 
 // Staging area of rrt_render_device_noalloc: the per-sample radiance slab of a render pass, held in the code object itself
 // so that the entry point never asks the runtime for memory.  Each GPU the library runs on holds its own copy until the
@@ -42,18 +27,6 @@ constexpr size_t kSlabCapBytes = 16ull << 30;  // default budget of the per-samp
 constexpr size_t kStaticSlabBytes = RRT_NOALLOC_STAGING_BYTES;
 static __device__ __align__(256) unsigned char scratch[kStaticSlabBytes];
 
-struct TraceArgs {
-    uint32_t W, H;
-    uint32_t first_sample;  // stream index of the pass's first sample
-    uint32_t n_samples;     // samples per pixel in this pass
-    uint32_t seed, bg, max_depth;
-    uint32_t tile_count, tile_index, tiles_x, n_tiles;  // 32x32-pixel tiles (multi-GPU sharding unit)
-    uint32_t n_t8;                                       // 8x8-pixel wave tiles owned by this call
-    uint32_t stack_depth;                                // LDS stack entries per lane (the cooperative-leaf area follows the stack)
-    uint32_t chunk;                                      // samples of each pixel handled by one wave item (divides kChunk)
-    uint32_t coop_lanes, shade_lanes;                    // k_trace_stream: paused / finished lanes that trigger a leaf / shading phase
-    uint32_t n_items;                                    // k_trace_pool: (tile, chunk) items of the pass, handed out through an atomic counter
-};
 
 // ---- the trace kernel for shallow trees (at most kDeepTreeNodes nodes; deep trees: k_trace_stream) ------------------------
 // ≙ main.rs:200-257 (thread_work) + aggregate.rs:16-105 (trace), for one pass of `n_samples` samples per pixel.
@@ -65,9 +38,6 @@ struct TraceArgs {
 // Path state (ray, throughput, RNG) lives in registers for the whole path; the BVH short stack is in LDS.
 // Every sample's radiance goes to slab[sample][y][x] (12 bytes per path); k_accumulate then adds a pixel's samples in
 // sample order, which makes the image independent of how samples were scheduled.
-#ifndef RRT_TRACE_MIN_WAVES
-#define RRT_TRACE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
-#endif
 template <int AABB_MODE, uint32_t FEAT, bool HARVEST = false>
 __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
     extern __shared__ uint32_t lds_stack[];
@@ -230,6 +200,7 @@ template <int AABB_MODE, uint32_t FEAT, bool HARVEST>
 __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters,
                                                                         uint32_t* __restrict__ item_counter) {
     extern __shared__ uint32_t lds_stack[];
+    constexpr bool kPlainRecord = (FEAT & (F_TEX | F_BUMP | F_MEDIUM)) == 0;  // one shading record per slot: see DScene::plain
     const uint32_t lane = threadIdx.x;
     uint32_t* stack = lds_stack + lane;
     unsigned char* area = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
@@ -360,7 +331,7 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
         if (phase == C_TRACE) {
             // ≙ aggregate.rs:24: the closest hit; then whatever decides which shading code the path needs
             float harvest[kHarvestLights];
-            const Hit hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST, kPoolSiftCap>(sc, have, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
+            const Hit hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST, kPoolSiftCap, false>(sc, have, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
             uint32_t cls = C_FREE;
             if (have) {
                 ++rays;
@@ -374,9 +345,11 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
                 uint32_t towards = 0u, light = 0u;
                 f3 radiance = mk3(0.0f, 0.0f, 0.0f);
                 if (depth < ta.max_depth && hit.slot >= 0) {
-                    const uint32_t type = RRT_PLAIN_TYPE(__float_as_uint(sc.c_plain()[2 * hit.slot].w));
-                    if (type == RRT_MAT_DIFFUSE_LIGHT) {  // material.rs:229-231: emission ends the path
-                        radiance = xyz(sc.c_plain()[2 * hit.slot + 1]);
+                    uint32_t type;  // Shape::get_material's type
+                    if (kPlainRecord) type = RRT_PLAIN_TYPE(__float_as_uint(sc.c_plain()[2 * hit.slot].w));
+                    else type = sc.c_materials()[RRT_INFO_MATERIAL(__float_as_uint(sc.c_slots()[3 * hit.slot + 1].w))].type;
+                    if (kPlainRecord && type == RRT_MAT_DIFFUSE_LIGHT) {  // material.rs:229-231: emission ends the path
+                        radiance = xyz(sc.c_plain()[2 * hit.slot + 1]);  // (a textured light's emission needs its hit properties: GEN)
                     } else if (type == RRT_MAT_LAMBERT) {
                         const LightChoice ch = draw_light_choice(sc, g);  // pdf.rs:110, 122: the bounce's first draws
                         cls = C_LCS;
@@ -428,6 +401,11 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
             hit.t = __uint_as_float(POOL(P_PDF_T, slot));
             hit.u = hit.v = 0.0f;
             hit.det = (hw & 1u) ? -1.0f : 1.0f;  // only the sign is used (by the hit properties)
+            if (FEAT & (F_TEX | F_BUMP)) {  // Triangle::get_hit_properties recomputes the barycentrics from the ray (shape.rs:384-400)
+                const cv4p cslots = sc.c_slots();
+                const v4f q0 = cslots[3 * hit.slot], q1 = cslots[3 * hit.slot + 1], q2 = cslots[3 * hit.slot + 2];
+                if (RRT_INFO_KIND(__float_as_uint(q1.w)) == RRT_KIND_TRIANGLE) triangle_uvdet(xyz(q0), xyz(q1), xyz(q2), r, &hit.u, &hit.v, &hit.det);
+            }
             const LightChoice chosen = {(meta & 16u) != 0u, hw >> 26};
             PendingPdf pend;
             pend.active = false;
@@ -482,158 +460,6 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
     }
 }
 
-// ---- the trace kernel for deep trees ------------------------------------------------------------------------
-// Same work and same results as k_trace, other schedule.  On a large mesh the rays of a wave need very
-// different numbers of node visits (a mean of 300 against 2 000 for the slowest lane of a wave on a 10 M-triangle mesh), and a
-// loop that runs query - shade - query in step leaves most lanes idle most of the time.  Here every lane is a small state
-// machine - FRESH (has a pool sample, no ray yet), WALK (visiting nodes), LEAF (paused at a leaf), READY (query finished) -
-// and the wave's loop does, each turn: one node for the WALK lanes; a cooperative leaf phase when enough lanes are paused;
-// a shading phase (shade, store, draw the next sample, make the camera ray) when enough lanes are READY or FRESH.  A lane
-// that finishes its query early is shaded and sent walking again while its neighbours are still in their queries.
-template <int AABB_MODE, uint32_t FEAT>
-__global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stream(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
-    extern __shared__ uint32_t lds_stack[];
-    const uint32_t lane = threadIdx.x;
-    // Workgroups go to the eight XCDs (each with an L2 of its own) round-robin by number.  Renumbered in groups of 128, the
-    // sixteen 8x8 tiles of one 32x32 tile land on ONE XCD, neighbouring 32x32 tiles on neighbouring XCDs (balance stays fine-grained).
-    uint32_t item = blockIdx.x;
-    if (item < (gridDim.x & ~127u)) item = (((item >> 7) * 8u + (item & 7u)) << 4) | ((item >> 3) & 15u);
-    const uint32_t chunk = item / ta.n_t8, j = item % ta.n_t8;
-    const uint32_t tile32 = ta.tile_index + (j >> 4) * ta.tile_count;
-    const uint32_t x0 = (tile32 % ta.tiles_x) * 32u + ((j & 3u) << 3);
-    const uint32_t y0 = (tile32 / ta.tiles_x) * 32u + (((j >> 2) & 3u) << 3);
-    const uint32_t s0 = chunk * ta.chunk;
-    const uint32_t ns = ta.n_samples - s0 < ta.chunk ? ta.n_samples - s0 : ta.chunk;
-    const uint32_t pool = ns * 64u;
-    uint32_t beyond[kMaxStackDepth];  // private memory; sized for any split of the stack the host may choose
-    const WalkStack stack = {lds_stack + lane, kTraceBlock, ta.stack_depth, beyond};
-    unsigned char* coop = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
-    enum : uint32_t { DEAD = 0, FRESH = 1, WALK = 2, LEAF = 3, READY = 4 };
-
-    uint32_t next = 64u;  // next undrawn pool index (wave-uniform)
-    uint32_t idx = lane;
-    uint32_t st = idx < pool ? FRESH : DEAD;
-    unsigned long long rays = 0, paths = 0;
-    uint32_t px = 0, py = 0, smp = 0, depth = 0;
-    Ray r;
-    f3 thr;
-    Rng g;
-    r.o = r.d = thr = mk3(0.0f, 0.0f, 0.0f);
-    g.s0 = g.s1 = 0;
-    Walk w;
-    walk_begin(sc, w, false, r, RRT_T_MAX);
-#ifdef RRT_PHASE_PROFILE
-    unsigned long long prof_nodes = 0, prof_pairs = 0, prof_steps = 0, prof_leaf_steps = 0, cyc_shade = 0, cyc_walk = 0, cyc_leaf = 0, n_shade = 0;
-    unsigned long long tick = __builtin_readcyclecounter();
-#define RRT_STREAM_TICK(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tick; tick = now_; }
-#else
-#define RRT_STREAM_TICK(acc)
-#endif
-    for (;;) {
-        const unsigned long long walking = RRT_BALLOT(st == WALK), paused = RRT_BALLOT(st == LEAF), waiting = RRT_BALLOT(st == READY || st == FRESH);
-        if ((walking | paused | waiting) == 0ull) break;
-        if (waiting != 0ull && ((uint32_t)__popcll(waiting) >= ta.shade_lanes || (walking | paused) == 0ull)) {
-            bool done = false;  // this lane needs a new sample
-            bool launch = false;  // this lane has a new ray to trace
-            if (st == READY) {
-                ++rays;
-                f3 radiance;
-                done = shade<FEAT>(sc, w.h, r, thr, g, depth, ta.max_depth, ta.bg, &radiance);
-                if (done) {
-                    f3 c = thr * radiance;
-                    float* q = slab + (((size_t)smp * ta.H + py) * ta.W + px) * 3;
-                    q[0] = c.x;
-                    q[1] = c.y;
-                    q[2] = c.z;
-                } else {
-                    ++depth;
-                    launch = true;
-                }
-            } else if (st == FRESH) {
-                px = x0 + (idx & 7u);
-                py = y0 + ((idx >> 3) & 7u);
-                smp = s0 + (idx >> 6);
-                if (px < ta.W && py < ta.H) {
-                    g = rng_seed(ta.seed, py * ta.W + px, ta.first_sample + smp);
-                    r = camera_ray(sc.cam, px, py, ta.W, ta.H, g);
-                    thr = mk3(1.0f, 1.0f, 1.0f);
-                    depth = 0;
-                    ++paths;
-                    launch = true;
-                } else {
-                    done = true;  // a pixel beyond the frame's edge: nothing to trace
-                }
-            }
-            if (launch) {
-                walk_begin(sc, w, true, r, RRT_T_MAX);
-                st = w.running ? WALK : READY;  // an empty scene answers at once
-            }
-            const unsigned long long finished = RRT_BALLOT(done);
-            if (done) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(finished >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)finished, 0u));
-                idx = next + rank;
-                st = idx < pool ? FRESH : DEAD;
-            }
-            next += (uint32_t)__popcll(finished);
-            RRT_STREAM_TICK(cyc_shade);
-            RRT_COUNT(n_shade, 1);
-            continue;
-        }
-        // several node steps before the wave looks at its lanes' states again: the bookkeeping of a turn (five ballots, the
-        // phase decisions) costs a quarter of a node step
-#pragma unroll 1
-        for (int rep = 0; rep < kWalkSteps; ++rep) {
-            if (st == WALK) {
-                RRT_COUNT(prof_nodes, 1);
-                walk_step<AABB_MODE>(sc, w, r, RRT_T_MIN, stack);
-                if (w.pending) {
-                    st = LEAF;
-                    RRT_COUNT(prof_pairs, w.n_pairs);
-                } else if (!w.running) st = READY;
-            }
-        }
-#ifdef RRT_PHASE_PROFILE
-        if (lane == 0) ++prof_steps;
-#endif
-        RRT_STREAM_TICK(cyc_walk);
-        const unsigned long long at_leaf = RRT_BALLOT(st == LEAF);
-        if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= ta.coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
-#ifdef RRT_PHASE_PROFILE
-            if (lane == 0) ++prof_leaf_steps;
-#endif
-            coop_leaves<FEAT, AABB_MODE == kAabbClean>(sc, r, RRT_T_MIN, g, depth, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
-            if (st == LEAF) {
-                walk_resume(w, stack);
-                st = w.running ? WALK : READY;
-            }
-            RRT_STREAM_TICK(cyc_leaf);
-        }
-    }
-#undef RRT_STREAM_TICK
-#ifdef RRT_PHASE_PROFILE
-    if (lane == 0) {
-        atomicAdd(&g_prof[4], cyc_shade);
-        atomicAdd(&g_prof[5], cyc_walk);
-        atomicAdd(&g_prof[6], cyc_leaf);
-        atomicAdd(&g_prof[7], n_shade);
-    }
-    atomicAdd(&g_prof[0], prof_nodes);
-    atomicAdd(&g_prof[1], prof_pairs);
-    atomicAdd(&g_prof[2], prof_steps);
-    atomicAdd(&g_prof[3], prof_leaf_steps);
-#endif
-    if (counters) {
-        for (int off = 32; off > 0; off >>= 1) {
-            rays += __shfl_down(rays, off);
-            paths += __shfl_down(paths, off);
-        }
-        if (lane == 0) {
-            atomicAdd(&counters[0], rays);
-            atomicAdd(&counters[1], paths);
-        }
-    }
-}
-
 // Adds each pixel's samples of one pass in sample order (main.rs:244-245: colors[p] = colors[p] + pixel_color).
 // One thread per float of the frame; reads are coalesced across the frame for every sample.
 __global__ void k_accumulate(const float* __restrict__ slab, uint32_t n_samples, size_t frame_floats, uint32_t W, uint32_t tiles_x, uint32_t tile_count,
@@ -669,76 +495,6 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, const float* __
     if (!active) return;
     prim[i] = h.slot >= 0 ? (int)__float_as_uint(sc.slots[3 * h.slot].w) : -1;
     t_hit[i] = h.t;
-}
-
-// The same for deep trees, on the schedule of k_trace_stream without the shading: a wave owns a run of consecutive rays, and a
-// lane whose query has ended writes its answer and fetches the next ray of the run at once (FRESH / READY lanes are served
-// when 16 of them wait), so no lane idles until the slowest query of the wave is through.
-template <int AABB_MODE>
-__global__ __launch_bounds__(kTraceBlock) void k_intersect_stream(DScene sc, const float* __restrict__ o, const float* __restrict__ d, size_t n, float t_min,
-                                                                  float t_max, uint32_t seed, uint32_t lds_entries, uint32_t run, uint32_t coop_lanes,
-                                                                  int* __restrict__ prim, float* __restrict__ t_hit) {
-    extern __shared__ uint32_t lds_stack[];
-    const uint32_t lane = threadIdx.x;
-    const size_t first = (size_t)blockIdx.x * run;
-    const uint32_t pool = n - first < (size_t)run ? (uint32_t)(n - first) : run;
-    uint32_t beyond[kMaxStackDepth];  // private memory: stack entries past the lds_entries ones kept in LDS
-    const WalkStack stack = {lds_stack + lane, kTraceBlock, lds_entries, beyond};
-    unsigned char* coop = (unsigned char*)(lds_stack + kTraceBlock * lds_entries);
-    enum : uint32_t { DEAD = 0, FRESH = 1, WALK = 2, LEAF = 3, READY = 4 };
-    uint32_t next = 64u;  // next unfetched ray of the run (wave-uniform)
-    uint32_t idx = lane;
-    uint32_t st = idx < pool ? FRESH : DEAD;
-    Ray r;
-    r.o = r.d = mk3(0.0f, 0.0f, 1.0f);
-    Rng g;
-    g.s0 = g.s1 = 0;
-    Walk w;
-    walk_begin(sc, w, false, r, t_max);
-    for (;;) {
-        const unsigned long long walking = RRT_BALLOT(st == WALK), paused = RRT_BALLOT(st == LEAF), waiting = RRT_BALLOT(st == READY || st == FRESH);
-        if ((walking | paused | waiting) == 0ull) break;
-        if (waiting != 0ull && ((uint32_t)__popcll(waiting) >= 16u || (walking | paused) == 0ull)) {
-            const bool done = st == READY;
-            if (done) {
-                const size_t i = first + idx;
-                prim[i] = w.h.slot >= 0 ? (int)__float_as_uint(sc.slots[3 * w.h.slot].w) : -1;
-                t_hit[i] = w.h.t;
-            }
-            const unsigned long long finished = RRT_BALLOT(done);
-            if (done) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(finished >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)finished, 0u));
-                idx = next + rank;
-                st = idx < pool ? FRESH : DEAD;
-            }
-            next += (uint32_t)__popcll(finished);
-            if (st == FRESH) {
-                const size_t i = first + idx;
-                r.o = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
-                r.d = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
-                g = rng_seed(seed, (uint32_t)i, 0);
-                walk_begin(sc, w, true, r, t_max);
-                st = w.running ? WALK : READY;  // an empty scene answers at once
-            }
-            continue;
-        }
-#pragma unroll 1
-        for (int rep = 0; rep < kWalkSteps; ++rep) {
-            if (st == WALK) {
-                walk_step<AABB_MODE>(sc, w, r, t_min, stack);
-                if (w.pending) st = LEAF;
-                else if (!w.running) st = READY;
-            }
-        }
-        const unsigned long long at_leaf = RRT_BALLOT(st == LEAF);
-        if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
-            coop_leaves<F_ALL, AABB_MODE == kAabbClean>(sc, r, t_min, g, 0, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
-            if (st == LEAF) {
-                walk_resume(w, stack);
-                st = w.running ? WALK : READY;
-            }
-        }
-    }
 }
 
 // ≙ main.rs:173-186
@@ -1473,11 +1229,9 @@ int rrt_intersect_batch_device(rrt_scene* s, const float* d_o, const float* d_d,
         const uint32_t lds_entries = s->stack_depth > s->lds_stack ? s->lds_stack : s->stack_depth;  // the rest in private memory
         const size_t lds = (size_t)kTraceBlock * lds_entries * sizeof(uint32_t) + kCoopBytesPerWave;
         const dim3 grid((unsigned)((n + run - 1) / run));
-#define RRT_LAUNCH_BATCH(MODE) hipLaunchKernelGGL((k_intersect_stream<MODE>), grid, dim3(kTraceBlock), lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, run, 24u, d_prim, d_t)
-        if (s->clean) RRT_LAUNCH_BATCH(kAabbClean);
-        else if (aabb_mode != RRT_AABB_TIGHT) RRT_LAUNCH_BATCH(RRT_AABB_REFERENCE);  // deep trees: the reference's test alone IS exhaustive (leaves are tested whole)
-        else RRT_LAUNCH_BATCH(RRT_AABB_TIGHT);
-#undef RRT_LAUNCH_BATCH
+        // deep trees: the reference's test alone IS exhaustive (leaves are tested whole)
+        const int mode = s->clean ? kAabbClean : (aabb_mode != RRT_AABB_TIGHT ? (int)RRT_AABB_REFERENCE : (int)RRT_AABB_TIGHT);
+        HIP_TRY(launch_intersect_stream(mode, grid, lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, run, 24u, d_prim, d_t));
     } else {
         const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
         const size_t lds = (size_t)kBlock * s->stack_depth * sizeof(uint32_t) + (size_t)(kBlock / 64) * kSiftBytesPerWave;
@@ -1628,50 +1382,48 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
         if (items > 0x7fffffffull) return rrt_set_error(RRT_ERR_LIMIT, "rrt_render: too many work items in one pass");
         const dim3 grid((unsigned)items);
         float* const pass_slab = static_staging ? slab : s->slab;
-        // shallow trees, plain feature set: the pooled schedule (k_trace_pool) - a persistent grid that hands the items out itself
+        // shallow trees: the pooled schedule (k_trace_pool) - a persistent grid that hands the items out itself
         if (p->aabb_mode == RRT_AABB_EXHAUSTIVE && !s->deep) {
             // the yardstick mode on a shallow tree: one kernel variant (every feature, one path per lane); speed is not its point
             hipLaunchKernelGGL((k_trace<kAabbExhaustive, F_ALL>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt);
-        } else if (s->pooling && !s->deep && (need & ~kPlain) == 0 && ta.max_depth <= kPoolMaxDepth && ta.n_samples <= kPoolMaxSamples &&
-                   s->d.n_lights <= kPoolMaxLights) {
+        } else if (s->pooling && !s->deep && ta.max_depth <= kPoolMaxDepth && ta.n_samples <= kPoolMaxSamples && s->d.n_lights <= kPoolMaxLights) {
             ta.n_items = (uint32_t)items;
             const dim3 pgrid((unsigned)(items < s->wave_places ? items : s->wave_places));
             if (s->harvest) ta.stack_depth = 0;  // a single leaf: the walk never pushes
             const size_t plds = (size_t)kTraceBlock * ta.stack_depth * sizeof(uint32_t) + kPoolBytesPerWave;
             HIP_TRY(hipMemsetAsync(s->d_items, 0, sizeof(uint32_t), st));
-#define RRT_LAUNCH_POOL(MODE, HARV) hipLaunchKernelGGL((k_trace_pool<MODE, kPlain, HARV>), pgrid, dim3(kTraceBlock), plds, st, s->d, ta, pass_slab, cnt, s->d_items)
-            if (p->aabb_mode == RRT_AABB_REFERENCE) {
-                if (s->harvest) RRT_LAUNCH_POOL(RRT_AABB_REFERENCE, true);
-                else RRT_LAUNCH_POOL(RRT_AABB_REFERENCE, false);
-            } else {
-                if (s->harvest) RRT_LAUNCH_POOL(RRT_AABB_TIGHT, true);
-                else RRT_LAUNCH_POOL(RRT_AABB_TIGHT, false);
-            }
+#define RRT_LAUNCH_POOL(MODE, FEAT, HARV) hipLaunchKernelGGL((k_trace_pool<MODE, FEAT, HARV>), pgrid, dim3(kTraceBlock), plds, st, s->d, ta, pass_slab, cnt, s->d_items)
+#define RRT_PICK_POOL(MODE)                                                  \
+    do {                                                                     \
+        if ((need & ~kPlain) == 0) {                                         \
+            if (s->harvest) RRT_LAUNCH_POOL(MODE, kPlain, true);             \
+            else RRT_LAUNCH_POOL(MODE, kPlain, false);                       \
+        } else if ((need & ~kTextured) == 0) RRT_LAUNCH_POOL(MODE, kTextured, false); \
+        else RRT_LAUNCH_POOL(MODE, F_ALL, false);                            \
+    } while (0)
+            if (p->aabb_mode == RRT_AABB_REFERENCE) RRT_PICK_POOL(RRT_AABB_REFERENCE);
+            else RRT_PICK_POOL(RRT_AABB_TIGHT);
+#undef RRT_PICK_POOL
 #undef RRT_LAUNCH_POOL
         } else {
 #define RRT_LAUNCH(MODE, FEAT) hipLaunchKernelGGL((k_trace<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt)
-#define RRT_LAUNCH_STREAM(MODE, FEAT) hipLaunchKernelGGL((k_trace_stream<MODE, FEAT>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt)
 #define RRT_PICK(MODE)                                                               \
     do {                                                                             \
-        if (s->deep) {                                                               \
-            if ((need & ~kPlain) == 0) RRT_LAUNCH_STREAM(MODE, kPlain);              \
-            else RRT_LAUNCH_STREAM(MODE, F_ALL);                                     \
-        } else if ((need & ~kPlain) == 0) {                                          \
+        if ((need & ~kPlain) == 0) {                                                 \
             if (s->harvest) hipLaunchKernelGGL((k_trace<MODE, kPlain, true>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt); \
             else RRT_LAUNCH(MODE, kPlain);                                           \
         }                                                                            \
         else if ((need & ~kTextured) == 0) RRT_LAUNCH(MODE, kTextured);              \
         else RRT_LAUNCH(MODE, F_ALL);                                                \
     } while (0)
-        if (s->clean) {
-            if ((need & ~kPlain) == 0) RRT_LAUNCH_STREAM(kAabbClean, kPlain);
-            else RRT_LAUNCH_STREAM(kAabbClean, F_ALL);
+        if (s->deep) {  // (clean trees are deep by definition)
+            const int mode = s->clean ? kAabbClean : (p->aabb_mode != RRT_AABB_TIGHT ? (int)RRT_AABB_REFERENCE : (int)RRT_AABB_TIGHT);
+            HIP_TRY(launch_trace_stream(mode, (need & ~kPlain) != 0, grid, lds, st, s->d, ta, pass_slab, cnt));
         } else if (p->aabb_mode != RRT_AABB_TIGHT) RRT_PICK(RRT_AABB_REFERENCE);
         else RRT_PICK(RRT_AABB_TIGHT);
         }
 #undef RRT_PICK
 #undef RRT_LAUNCH
-#undef RRT_LAUNCH_STREAM
         HIP_TRY(hipGetLastError());
         if (ev) HIP_TRY(hipEventRecord(ev[1], st));
         hipLaunchKernelGGL(k_accumulate, dim3((unsigned)((frame_floats + 255) / 256)), dim3(256), 0, st, pass_slab, ta.n_samples, frame_floats, ta.W,

@@ -1,0 +1,262 @@
+// The kernels for deep trees (more than 16 nodes, or a clean tree): the streaming path tracer and the streaming ray batch.
+#include <hip/hip_runtime.h>
+
+#include "rrt_device.hpp"
+#include "rrt_launch.hpp"
+
+using namespace rrt;
+
+namespace {
+
+// ---- the trace kernel for deep trees ------------------------------------------------------------------------
+// Same work and same results as k_trace, other schedule.  On a large mesh the rays of a wave need very
+// different numbers of node visits (a mean of 300 against 2 000 for the slowest lane of a wave on a 10 M-triangle mesh), and a
+// loop that runs query - shade - query in step leaves most lanes idle most of the time.  Here every lane is a small state
+// machine - FRESH (has a pool sample, no ray yet), WALK (visiting nodes), LEAF (paused at a leaf), READY (query finished) -
+// and the wave's loop does, each turn: one node for the WALK lanes; a cooperative leaf phase when enough lanes are paused;
+// a shading phase (shade, store, draw the next sample, make the camera ray) when enough lanes are READY or FRESH.  A lane
+// that finishes its query early is shaded and sent walking again while its neighbours are still in their queries.
+template <int AABB_MODE, uint32_t FEAT>
+__global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stream(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t lane = threadIdx.x;
+    // Workgroups go to the eight XCDs (each with an L2 of its own) round-robin by number.  Renumbered in groups of 128, the
+    // sixteen 8x8 tiles of one 32x32 tile land on ONE XCD, neighbouring 32x32 tiles on neighbouring XCDs (balance stays fine-grained).
+    uint32_t item = blockIdx.x;
+    if (item < (gridDim.x & ~127u)) item = (((item >> 7) * 8u + (item & 7u)) << 4) | ((item >> 3) & 15u);
+    const uint32_t chunk = item / ta.n_t8, j = item % ta.n_t8;
+    const uint32_t tile32 = ta.tile_index + (j >> 4) * ta.tile_count;
+    const uint32_t x0 = (tile32 % ta.tiles_x) * 32u + ((j & 3u) << 3);
+    const uint32_t y0 = (tile32 / ta.tiles_x) * 32u + (((j >> 2) & 3u) << 3);
+    const uint32_t s0 = chunk * ta.chunk;
+    const uint32_t ns = ta.n_samples - s0 < ta.chunk ? ta.n_samples - s0 : ta.chunk;
+    const uint32_t pool = ns * 64u;
+    uint32_t beyond[kMaxStackDepth];  // private memory; sized for any split of the stack the host may choose
+    const WalkStack stack = {lds_stack + lane, kTraceBlock, ta.stack_depth, beyond};
+    unsigned char* coop = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
+    enum : uint32_t { DEAD = 0, FRESH = 1, WALK = 2, LEAF = 3, READY = 4 };
+
+    uint32_t next = 64u;  // next undrawn pool index (wave-uniform)
+    uint32_t idx = lane;
+    uint32_t st = idx < pool ? FRESH : DEAD;
+    unsigned long long rays = 0, paths = 0;
+    uint32_t px = 0, py = 0, smp = 0, depth = 0;
+    Ray r;
+    f3 thr;
+    Rng g;
+    r.o = r.d = thr = mk3(0.0f, 0.0f, 0.0f);
+    g.s0 = g.s1 = 0;
+    Walk w;
+    walk_begin(sc, w, false, r, RRT_T_MAX);
+#ifdef RRT_PHASE_PROFILE
+    unsigned long long prof_nodes = 0, prof_pairs = 0, prof_steps = 0, prof_leaf_steps = 0, cyc_shade = 0, cyc_walk = 0, cyc_leaf = 0, n_shade = 0;
+    unsigned long long tick = __builtin_readcyclecounter();
+#define RRT_STREAM_TICK(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tick; tick = now_; }
+#else
+#define RRT_STREAM_TICK(acc)
+#endif
+    for (;;) {
+        const unsigned long long walking = RRT_BALLOT(st == WALK), paused = RRT_BALLOT(st == LEAF), waiting = RRT_BALLOT(st == READY || st == FRESH);
+        if ((walking | paused | waiting) == 0ull) break;
+        if (waiting != 0ull && ((uint32_t)__popcll(waiting) >= ta.shade_lanes || (walking | paused) == 0ull)) {
+            bool done = false;  // this lane needs a new sample
+            bool launch = false;  // this lane has a new ray to trace
+            if (st == READY) {
+                ++rays;
+                f3 radiance;
+                done = shade<FEAT>(sc, w.h, r, thr, g, depth, ta.max_depth, ta.bg, &radiance);
+                if (done) {
+                    f3 c = thr * radiance;
+                    float* q = slab + (((size_t)smp * ta.H + py) * ta.W + px) * 3;
+                    q[0] = c.x;
+                    q[1] = c.y;
+                    q[2] = c.z;
+                } else {
+                    ++depth;
+                    launch = true;
+                }
+            } else if (st == FRESH) {
+                px = x0 + (idx & 7u);
+                py = y0 + ((idx >> 3) & 7u);
+                smp = s0 + (idx >> 6);
+                if (px < ta.W && py < ta.H) {
+                    g = rng_seed(ta.seed, py * ta.W + px, ta.first_sample + smp);
+                    r = camera_ray(sc.cam, px, py, ta.W, ta.H, g);
+                    thr = mk3(1.0f, 1.0f, 1.0f);
+                    depth = 0;
+                    ++paths;
+                    launch = true;
+                } else {
+                    done = true;  // a pixel beyond the frame's edge: nothing to trace
+                }
+            }
+            if (launch) {
+                walk_begin(sc, w, true, r, RRT_T_MAX);
+                st = w.running ? WALK : READY;  // an empty scene answers at once
+            }
+            const unsigned long long finished = RRT_BALLOT(done);
+            if (done) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(finished >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)finished, 0u));
+                idx = next + rank;
+                st = idx < pool ? FRESH : DEAD;
+            }
+            next += (uint32_t)__popcll(finished);
+            RRT_STREAM_TICK(cyc_shade);
+            RRT_COUNT(n_shade, 1);
+            continue;
+        }
+        // several node steps before the wave looks at its lanes' states again: the bookkeeping of a turn (five ballots, the
+        // phase decisions) costs a quarter of a node step
+#pragma unroll 1
+        for (int rep = 0; rep < kWalkSteps; ++rep) {
+            if (st == WALK) {
+                RRT_COUNT(prof_nodes, 1);
+                walk_step<AABB_MODE>(sc, w, r, RRT_T_MIN, stack);
+                if (w.pending) {
+                    st = LEAF;
+                    RRT_COUNT(prof_pairs, w.n_pairs);
+                } else if (!w.running) st = READY;
+            }
+        }
+#ifdef RRT_PHASE_PROFILE
+        if (lane == 0) ++prof_steps;
+#endif
+        RRT_STREAM_TICK(cyc_walk);
+        const unsigned long long at_leaf = RRT_BALLOT(st == LEAF);
+        if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= ta.coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
+#ifdef RRT_PHASE_PROFILE
+            if (lane == 0) ++prof_leaf_steps;
+#endif
+            coop_leaves<FEAT, AABB_MODE == kAabbClean>(sc, r, RRT_T_MIN, g, depth, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
+            if (st == LEAF) {
+                walk_resume(w, stack);
+                st = w.running ? WALK : READY;
+            }
+            RRT_STREAM_TICK(cyc_leaf);
+        }
+    }
+#undef RRT_STREAM_TICK
+#ifdef RRT_PHASE_PROFILE
+    if (lane == 0) {
+        atomicAdd(&g_prof[4], cyc_shade);
+        atomicAdd(&g_prof[5], cyc_walk);
+        atomicAdd(&g_prof[6], cyc_leaf);
+        atomicAdd(&g_prof[7], n_shade);
+    }
+    atomicAdd(&g_prof[0], prof_nodes);
+    atomicAdd(&g_prof[1], prof_pairs);
+    atomicAdd(&g_prof[2], prof_steps);
+    atomicAdd(&g_prof[3], prof_leaf_steps);
+#endif
+    if (counters) {
+        for (int off = 32; off > 0; off >>= 1) {
+            rays += __shfl_down(rays, off);
+            paths += __shfl_down(paths, off);
+        }
+        if (lane == 0) {
+            atomicAdd(&counters[0], rays);
+            atomicAdd(&counters[1], paths);
+        }
+    }
+}
+
+// The same for deep trees, on the schedule of k_trace_stream without the shading: a wave owns a run of consecutive rays, and a
+// lane whose query has ended writes its answer and fetches the next ray of the run at once (FRESH / READY lanes are served
+// when 16 of them wait), so no lane idles until the slowest query of the wave is through.
+template <int AABB_MODE>
+__global__ __launch_bounds__(kTraceBlock) void k_intersect_stream(DScene sc, const float* __restrict__ o, const float* __restrict__ d, size_t n, float t_min,
+                                                                  float t_max, uint32_t seed, uint32_t lds_entries, uint32_t run, uint32_t coop_lanes,
+                                                                  int* __restrict__ prim, float* __restrict__ t_hit) {
+    extern __shared__ uint32_t lds_stack[];
+    const uint32_t lane = threadIdx.x;
+    const size_t first = (size_t)blockIdx.x * run;
+    const uint32_t pool = n - first < (size_t)run ? (uint32_t)(n - first) : run;
+    uint32_t beyond[kMaxStackDepth];  // private memory: stack entries past the lds_entries ones kept in LDS
+    const WalkStack stack = {lds_stack + lane, kTraceBlock, lds_entries, beyond};
+    unsigned char* coop = (unsigned char*)(lds_stack + kTraceBlock * lds_entries);
+    enum : uint32_t { DEAD = 0, FRESH = 1, WALK = 2, LEAF = 3, READY = 4 };
+    uint32_t next = 64u;  // next unfetched ray of the run (wave-uniform)
+    uint32_t idx = lane;
+    uint32_t st = idx < pool ? FRESH : DEAD;
+    Ray r;
+    r.o = r.d = mk3(0.0f, 0.0f, 1.0f);
+    Rng g;
+    g.s0 = g.s1 = 0;
+    Walk w;
+    walk_begin(sc, w, false, r, t_max);
+    for (;;) {
+        const unsigned long long walking = RRT_BALLOT(st == WALK), paused = RRT_BALLOT(st == LEAF), waiting = RRT_BALLOT(st == READY || st == FRESH);
+        if ((walking | paused | waiting) == 0ull) break;
+        if (waiting != 0ull && ((uint32_t)__popcll(waiting) >= 16u || (walking | paused) == 0ull)) {
+            const bool done = st == READY;
+            if (done) {
+                const size_t i = first + idx;
+                prim[i] = w.h.slot >= 0 ? (int)__float_as_uint(sc.slots[3 * w.h.slot].w) : -1;
+                t_hit[i] = w.h.t;
+            }
+            const unsigned long long finished = RRT_BALLOT(done);
+            if (done) {
+                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(finished >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)finished, 0u));
+                idx = next + rank;
+                st = idx < pool ? FRESH : DEAD;
+            }
+            next += (uint32_t)__popcll(finished);
+            if (st == FRESH) {
+                const size_t i = first + idx;
+                r.o = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
+                r.d = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
+                g = rng_seed(seed, (uint32_t)i, 0);
+                walk_begin(sc, w, true, r, t_max);
+                st = w.running ? WALK : READY;  // an empty scene answers at once
+            }
+            continue;
+        }
+#pragma unroll 1
+        for (int rep = 0; rep < kWalkSteps; ++rep) {
+            if (st == WALK) {
+                walk_step<AABB_MODE>(sc, w, r, t_min, stack);
+                if (w.pending) st = LEAF;
+                else if (!w.running) st = READY;
+            }
+        }
+        const unsigned long long at_leaf = RRT_BALLOT(st == LEAF);
+        if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
+            coop_leaves<F_ALL, AABB_MODE == kAabbClean>(sc, r, t_min, g, 0, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
+            if (st == LEAF) {
+                walk_resume(w, stack);
+                st = w.running ? WALK : READY;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+namespace rrt {
+
+hipError_t launch_trace_stream(int mode, bool every_feature, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const TraceArgs& ta, float* slab,
+                               unsigned long long* counters) {
+    constexpr uint32_t kPlain = F_SPHERE;
+#define RRT_GO(MODE)                                                                                                                       \
+    do {                                                                                                                                   \
+        if (every_feature) hipLaunchKernelGGL((k_trace_stream<MODE, F_ALL>), grid, dim3(kTraceBlock), lds, st, sc, ta, slab, counters);   \
+        else hipLaunchKernelGGL((k_trace_stream<MODE, kPlain>), grid, dim3(kTraceBlock), lds, st, sc, ta, slab, counters);                \
+    } while (0)
+    if (mode == kAabbClean) RRT_GO(kAabbClean);
+    else if (mode == RRT_AABB_REFERENCE) RRT_GO(RRT_AABB_REFERENCE);
+    else RRT_GO(RRT_AABB_TIGHT);
+#undef RRT_GO
+    return hipGetLastError();
+}
+
+hipError_t launch_intersect_stream(int mode, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const float* o, const float* d, size_t n, float t_min,
+                                   float t_max, uint32_t seed, uint32_t lds_entries, uint32_t run, uint32_t coop_lanes, int* prim, float* t_hit) {
+#define RRT_GO(MODE) hipLaunchKernelGGL((k_intersect_stream<MODE>), grid, dim3(kTraceBlock), lds, st, sc, o, d, n, t_min, t_max, seed, lds_entries, run, coop_lanes, prim, t_hit)
+    if (mode == kAabbClean) RRT_GO(kAabbClean);
+    else if (mode == RRT_AABB_REFERENCE) RRT_GO(RRT_AABB_REFERENCE);
+    else RRT_GO(RRT_AABB_TIGHT);
+#undef RRT_GO
+    return hipGetLastError();
+}
+
+}  // namespace rrt

@@ -518,7 +518,7 @@ RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max
     __threadfence_block();
 }
 
-template <int AABB_MODE, uint32_t FEAT, bool HARVEST = false, uint32_t CAP = kSiftCap>
+template <int AABB_MODE, uint32_t FEAT, bool HARVEST = false, uint32_t CAP = kSiftCap, bool WANT_UV = true>
 RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack,
                              uint32_t stride, unsigned char* area, float* harvest = nullptr) {
     // Must be called by all 64 lanes of the wave (the dense phase addresses lanes by number); lanes without a ray pass
@@ -654,8 +654,9 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
         atomicAdd(&g_prof[7], prof_phases);
     }
 #endif
-    if ((FEAT & (F_TEX | F_BUMP)) && h.slot >= 0) {
+    if (WANT_UV && (FEAT & (F_TEX | F_BUMP)) && h.slot >= 0) {
         // Triangle::get_hit_properties recomputes the barycentrics from the ray (shape.rs:384-400); so does this path
+        // (callers that shade later, from a stored hit, pass WANT_UV = false and do this themselves)
         const cv4p cslots = sc.c_slots();
         const v4f q0 = cslots[3 * h.slot], q1 = cslots[3 * h.slot + 1], q2 = cslots[3 * h.slot + 2];
         if (RRT_INFO_KIND(__float_as_uint(q1.w)) == RRT_KIND_TRIANGLE) triangle_uvdet(xyz(q0), xyz(q1), xyz(q2), r, &h.u, &h.v, &h.det);

@@ -424,7 +424,7 @@ def test_resolve_rgb8(gpu):
 
 @pytest.mark.parametrize("name,W,H,spp", [("Cornell_Box_With_Sphere.json", 200, 136, 20), ("Cornell_Box.json", 333, 222, 9), ("Cornell_Box.json", 64, 64, 300)])
 def test_pooled_and_lockstep_schedules_give_the_oracle_frame(gpu, name, W, H, spp):
-    """Plain shallow scenes are traced by k_trace_pool (128 paths of a wave pooled in LDS, one kind of work per step) unless
+    """Shallow scenes are traced by k_trace_pool (128 paths of a wave pooled in LDS, one kind of work per step) unless
     rrt_scene_set_pooling(0) asks for k_trace (one path per lane): both must give the oracle's frame bit for bit, in both box-test
     modes, over ragged frames (partial 8x8 and 32x32 tiles), across item boundaries (more samples than a 64-sample chunk) and
     with interleaved tiles."""
@@ -445,6 +445,34 @@ def test_pooled_and_lockstep_schedules_give_the_oracle_frame(gpu, name, W, H, sp
     g.set_staging_limit(W * H * 12 * 7)  # seven samples per pass: many short launches of the persistent grid
     img, st = g.render(seed=12)
     assert ((bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))).all() and st["rays"] == int(st_ref[0])
+
+
+@pytest.mark.parametrize("name,W,H,spp,bg", [("Materials.json", 150, 90, 12, rrt.BG_SKY), ("Globe.json", 131, 77, 8, rrt.BG_SKY),
+                                             ("Example_Spec.json", 120, 72, 10, rrt.BG_SKY), ("Example_Spec.json", 64, 40, 70, rrt.BG_BLACK)])
+def test_pooled_and_lockstep_schedules_on_textured_scenes_and_media(gpu, name, W, H, spp, bg):
+    """The pooled schedule's textured and full variants (image / procedural textures, bump maps, textured lights, a constant
+    medium with its keyed draw, metal and glass) against the one-path-per-lane kernel and the oracle."""
+    o, g = both(name, resolution_x=W, resolution_y=H, samples=spp)
+    ref, st_ref = o.render(W, H, spp, seed=21, bg=bg, threads=min(16, len(__import__("os").sched_getaffinity(0))))
+    for pooled in (True, False):
+        g.set_pooling(pooled)
+        for mode in (rrt.AABB_TIGHT, rrt.AABB_REFERENCE):
+            img, st = g.render(seed=21, background=bg, aabb_mode=mode)
+            same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+            assert same.all(), "%d of %d values differ (pooled %s, mode %d)" % ((~same).sum(), same.size, pooled, mode)
+            assert st["rays"] == int(st_ref[0]) and st["paths"] == W * H * spp
+
+
+def test_pooled_schedule_with_scaled_spheres_and_media(gpu):
+    d = synth.spheres_desc(media=6)
+    o = orc.OracleScene(d)
+    g = rrt.Scene(synth.host_scene(d))
+    ref, st_ref = o.render(48, 40, 6, seed=8, bg=rrt.BG_SKY)
+    for pooled in (True, False):
+        g.set_pooling(pooled)
+        img, st = g.render(samples=6, seed=8, background=rrt.BG_SKY)
+        same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all() and st["rays"] == int(st_ref[0]), pooled
 
 
 def test_pooled_schedule_with_a_depth_limit_and_many_lights(gpu):
