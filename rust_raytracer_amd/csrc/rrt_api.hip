@@ -1331,19 +1331,32 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
     const uint64_t n_passes = (plan.spp + per_pass - 1) / per_pass;
     const uint64_t even = ((plan.spp + n_passes - 1) / n_passes + kChunk - 1) / kChunk * kChunk;
     if (even < per_pass) per_pass = even;
-    const size_t need_bytes = (size_t)per_pass * frame_bytes;
     float* const slab = static_staging ? s->static_slab : nullptr;
     if (static_staging) {
         if (!slab) return rrt_set_error(RRT_ERR_DEVICE, "rrt_render_device_noalloc: the built-in staging area was not found on this device");
-    } else if (s->slab_bytes < need_bytes) {
+    } else if (s->slab_bytes < (size_t)per_pass * frame_bytes) {
         if (s->slab) {
             HIP_TRY(hipDeviceSynchronize());  // earlier renders on any stream may still read the old buffer
             HIP_TRY(hipFree(s->slab));
             s->slab = nullptr;
             s->slab_bytes = 0;
         }
-        HIP_TRY(hipMalloc((void**)&s->slab, need_bytes));
-        s->slab_bytes = need_bytes;
+        // A device short of memory (other handles, other processes, a smaller board) gets more, smaller passes instead of an error:
+        // the frame is the same bits whatever the split (k_accumulate adds in sample order).
+        for (;;) {
+            const size_t want = (size_t)per_pass * frame_bytes;
+            const hipError_t e = hipMalloc((void**)&s->slab, want);
+            if (e == hipSuccess) {
+                s->slab_bytes = want;
+                break;
+            }
+            (void)hipGetLastError();  // the failed allocation must not show up as the next launch's error
+            s->slab = nullptr;
+            if (e != hipErrorOutOfMemory || per_pass == 1)
+                return rrt_set_error(RRT_ERR_DEVICE, "rrt_render: no device memory for the staging buffer of one sample per pixel (" + std::to_string(want) +
+                                                         " bytes): " + hipGetErrorString(e));
+            per_pass = per_pass / 2 >= kChunk ? per_pass / 2 / kChunk * kChunk : (per_pass + 1) / 2;
+        }
     }
     ta.stack_depth = s->deep && s->stack_depth > s->lds_stack ? s->lds_stack : s->stack_depth;
     const size_t lds = (size_t)kTraceBlock * ta.stack_depth * sizeof(uint32_t) + (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave + kHarvestBytesPerWave);
