@@ -67,20 +67,9 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
     pend.active = false;
     pend.numerator = mk3(0.0f, 0.0f, 0.0f);
     pend.scatter_pdf = 0.0f;
-#ifdef RRT_PHASE_PROFILE
-    unsigned long long pc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#define RRT_TICK(i) { unsigned long long now_ = __builtin_readcyclecounter(); pc[i] += now_ - tick_; tick_ = now_; }
-    unsigned long long tick_ = __builtin_readcyclecounter();
-#else
-#define RRT_TICK(i)
-#endif
     // The closest-hit query is a whole-wave operation, so the loop runs until every lane's pool share is done and lanes
     // without a path keep taking part (valid = false).
     while (RRT_BALLOT(alive) != 0ull) {
-#ifdef RRT_PHASE_PROFILE
-        pc[4] += 1;
-        pc[5] += __popcll(__ballot(fresh));
-#endif
         if (fresh && alive) {
             px = x0 + (idx & 7u);
             py = y0 + ((idx >> 3) & 7u);
@@ -96,14 +85,12 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
             }
             fresh = false;
         }
-        RRT_TICK(0)
         bool done = true;
         {
             Hit hit;
             unsigned char* area = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
             float harvest[kHarvestLights];
             hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
-            RRT_TICK(1)
             if (valid) {
                 ++rays;
                 f3 radiance;
@@ -113,11 +100,6 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
                     pend.active = false;
                 }
                 done = shade<FEAT, HARVEST>(sc, hit, r, thr, g, depth, ta.max_depth, ta.bg, &radiance, &pend);
-                RRT_TICK(2)
-#ifdef RRT_PHASE_PROFILE
-                pc[6] += __popcll(__ballot(true));
-                pc[7] += __popcll(__ballot(done));
-#endif
                 if (done) {
                     f3 c = thr * radiance;
                     float* q = slab + (((size_t)smp * ta.H + py) * ta.W + px) * 3;
@@ -138,12 +120,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
             if (!alive) valid = false;
         }
         next += (uint32_t)__popcll(finished);
-        RRT_TICK(3)
     }
-#ifdef RRT_PHASE_PROFILE
-    if (counters && lane == 0)
-        for (int i = 0; i < 8; ++i) atomicAdd(&counters[2 + i], pc[i]);
-#endif
     if (counters) {
         for (int off = 32; off > 0; off >>= 1) {
             rays += __shfl_down(rays, off);
@@ -175,9 +152,6 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
 // bounce either way), every sample still goes to slab[sample][y][x], and k_accumulate adds in sample order: bit-identical frames.
 // Waves are persistent: the grid fills the chip once and a wave that has drawn all samples of its (tile, chunk) item takes the
 // next item from an atomic counter, so a launch has no ramp of short-lived blocks and its tail is one item long.
-#ifdef RRT_PHASE_PROFILE
-__device__ unsigned long long g_pool_prof[24];  // profiling build only: per kind of work, steps | paths served | cycles
-#endif
 #ifndef RRT_POOL
 #define RRT_POOL 128
 #endif
@@ -214,21 +188,9 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
     bool exhausted = false;                                    // no items left in the frame
     unsigned long long rays = 0, paths = 0;
     const size_t frame_pixels = (size_t)ta.W * ta.H;
-#ifdef RRT_PHASE_PROFILE
-    unsigned long long prof_steps[kClasses] = {0, 0, 0, 0, 0}, prof_lanes[kClasses] = {0, 0, 0, 0, 0}, prof_cycles[kClasses] = {0, 0, 0, 0, 0};
-    unsigned long long prof_tick = __builtin_readcyclecounter();
-    uint32_t prof_phase = kClasses;
-#define RRT_POOL_PROFILE_STEP()                                                         \
-    {                                                                                   \
-        const unsigned long long now_ = __builtin_readcyclecounter();                   \
-        _Pragma("unroll") for (uint32_t c_ = 0; c_ < kClasses; ++c_) if (prof_phase == c_) prof_cycles[c_] += now_ - prof_tick; \
-        prof_tick = now_;                                                               \
-    }
-#else
-#define RRT_POOL_PROFILE_STEP()
-#endif
+    PoolProbe<kClasses> probe;
     for (;;) {
-        RRT_POOL_PROFILE_STEP()
+        probe.turn();
         // ---- which kind of work: a kind with a full wave of paths waiting (ending paths first: they free slots), else fresh
         // samples while slots are free, else the fullest kind
         uint32_t phase = kClasses;
@@ -261,15 +223,7 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
             n += (uint32_t)__popcll(bal);
         }
         if (n > 64u) n = 64u;
-#ifdef RRT_PHASE_PROFILE
-        prof_phase = phase;
-#pragma unroll
-        for (uint32_t c = 0; c < kClasses; ++c)
-            if (phase == c) {
-                prof_steps[c] += 1;
-                prof_lanes[c] += n;
-            }
-#endif
+        probe.chosen(phase, n);
         __threadfence_block();
         bool have = lane < n;
         const uint32_t slot = have ? list[lane] : 0u;
@@ -440,14 +394,7 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
         __threadfence_block();
     }
 #undef POOL
-#ifdef RRT_PHASE_PROFILE
-    if (lane == 0)
-        for (uint32_t c = 0; c < kClasses; ++c) {
-            atomicAdd(&g_pool_prof[c], prof_steps[c]);
-            atomicAdd(&g_pool_prof[kClasses + c], prof_lanes[c]);
-            atomicAdd(&g_pool_prof[2 * kClasses + c], prof_cycles[c]);
-        }
-#endif
+    probe.store(lane);
     if (counters) {
         for (int off = 32; off > 0; off >>= 1) {
             rays += __shfl_down(rays, off);
@@ -1808,6 +1755,9 @@ extern "C" int rrt_profile_read(uint64_t* out8) {
     HIP_TRY(hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_prof), 64));
     uint64_t zero[8] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, 64));
+    uint64_t deep[8];  // the deep-tree kernels count in their own translation unit's copy
+    HIP_TRY(profile_take_stream(deep));
+    for (int i = 0; i < 8; ++i) out8[i] += deep[i];
     return RRT_OK;
 }
 #endif

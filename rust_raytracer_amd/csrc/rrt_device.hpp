@@ -4,5 +4,6 @@
 //   rrt_primitives.hpp  exact reciprocal, triangle / sphere / medium tests, bounding-box tests
 //   rrt_traversal.hpp   closest-hit queries (pair test, cooperative leaves, node walk, sifting)
 //   rrt_shading.hpp     hit properties, light mixture, materials, one step of aggregate::trace
+// (rrt_profile.hpp: the probes of the profiling build, empty otherwise)
 #pragma once
 #include "rrt_shading.hpp"

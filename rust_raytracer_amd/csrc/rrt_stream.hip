@@ -48,13 +48,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
     g.s0 = g.s1 = 0;
     Walk w;
     walk_begin(sc, w, false, r, RRT_T_MAX);
-#ifdef RRT_PHASE_PROFILE
-    unsigned long long prof_nodes = 0, prof_pairs = 0, prof_steps = 0, prof_leaf_steps = 0, cyc_shade = 0, cyc_walk = 0, cyc_leaf = 0, n_shade = 0;
-    unsigned long long tick = __builtin_readcyclecounter();
-#define RRT_STREAM_TICK(acc) { const unsigned long long now_ = __builtin_readcyclecounter(); acc += now_ - tick; tick = now_; }
-#else
-#define RRT_STREAM_TICK(acc)
-#endif
+    StreamProbe probe;
     for (;;) {
         const unsigned long long walking = RRT_BALLOT(st == WALK), paused = RRT_BALLOT(st == LEAF), waiting = RRT_BALLOT(st == READY || st == FRESH);
         if ((walking | paused | waiting) == 0ull) break;
@@ -101,8 +95,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
                 st = idx < pool ? FRESH : DEAD;
             }
             next += (uint32_t)__popcll(finished);
-            RRT_STREAM_TICK(cyc_shade);
-            RRT_COUNT(n_shade, 1);
+            probe.shaded();
             continue;
         }
         // several node steps before the wave looks at its lanes' states again: the bookkeeping of a turn (five ballots, the
@@ -110,44 +103,27 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
 #pragma unroll 1
         for (int rep = 0; rep < kWalkSteps; ++rep) {
             if (st == WALK) {
-                RRT_COUNT(prof_nodes, 1);
+                probe.node_visited();
                 walk_step<AABB_MODE>(sc, w, r, RRT_T_MIN, stack);
                 if (w.pending) {
                     st = LEAF;
-                    RRT_COUNT(prof_pairs, w.n_pairs);
+                    probe.leaf_reached(w.n_pairs);
                 } else if (!w.running) st = READY;
             }
         }
-#ifdef RRT_PHASE_PROFILE
-        if (lane == 0) ++prof_steps;
-#endif
-        RRT_STREAM_TICK(cyc_walk);
+        probe.walked(lane);
         const unsigned long long at_leaf = RRT_BALLOT(st == LEAF);
         if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= ta.coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
-#ifdef RRT_PHASE_PROFILE
-            if (lane == 0) ++prof_leaf_steps;
-#endif
+            probe.leaf_phase_begins(lane);
             coop_leaves<FEAT, AABB_MODE == kAabbClean>(sc, r, RRT_T_MIN, g, depth, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
             if (st == LEAF) {
                 walk_resume(w, stack);
                 st = w.running ? WALK : READY;
             }
-            RRT_STREAM_TICK(cyc_leaf);
+            probe.leaf_phase_done();
         }
     }
-#undef RRT_STREAM_TICK
-#ifdef RRT_PHASE_PROFILE
-    if (lane == 0) {
-        atomicAdd(&g_prof[4], cyc_shade);
-        atomicAdd(&g_prof[5], cyc_walk);
-        atomicAdd(&g_prof[6], cyc_leaf);
-        atomicAdd(&g_prof[7], n_shade);
-    }
-    atomicAdd(&g_prof[0], prof_nodes);
-    atomicAdd(&g_prof[1], prof_pairs);
-    atomicAdd(&g_prof[2], prof_steps);
-    atomicAdd(&g_prof[3], prof_leaf_steps);
-#endif
+    probe.store(lane);
     if (counters) {
         for (int off = 32; off > 0; off >>= 1) {
             rays += __shfl_down(rays, off);
@@ -258,5 +234,15 @@ hipError_t launch_intersect_stream(int mode, dim3 grid, size_t lds, hipStream_t 
 #undef RRT_GO
     return hipGetLastError();
 }
+
+#ifdef RRT_PHASE_PROFILE
+hipError_t profile_take_stream(uint64_t* out8) {
+    hipError_t e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_prof), 64);
+    const uint64_t zero[8] = {0};
+    if (e == hipSuccess) e = hipMemcpyToSymbol(HIP_SYMBOL(g_prof), zero, 64);
+    return e;
+}
+#endif
 
 }  // namespace rrt

@@ -3,6 +3,7 @@
 // Each function names the reference code it computes (paths relative to the reference root).
 #pragma once
 #include "rrt_primitives.hpp"
+#include "rrt_profile.hpp"
 
 namespace rrt {
 
@@ -18,10 +19,6 @@ enum : uint32_t {
 };
 
 
-#ifdef RRT_PHASE_PROFILE
-// profiling build only: per-lane node visits, per-lane pair tests, wave-level node steps, wave-level pair steps
-__device__ unsigned long long g_prof[8];  // [4..7]: sift phase (filter steps, items, dense groups, phases), counted per wave
-#endif
 
 // ---- closest hit: BVH::hit (aggregate.rs:324-401) with List::hit (aggregate.rs:144-165) in the leaves ------------
 struct Hit {
@@ -161,11 +158,6 @@ RRT_DEV void test_pair(const DScene& sc, cv4p rec, const Ray& r, float t_min, co
 // node's `a` is its first pair and the low bits of `b` its number of pairs.  The two primitives of a pair are in leaf
 // order (A before B) but pairs need not be: every comparison below orders candidates by (distance, slot), and slots are
 // numbered in leaf order.
-#ifdef RRT_PHASE_PROFILE
-#define RRT_COUNT(x, n) x += (n)
-#else
-#define RRT_COUNT(x, n)
-#endif
 
 // monotone map float -> uint (all non-NaN values), and back
 RRT_DEV uint32_t ord_bits(float f) {
@@ -539,9 +531,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
     if (!(__builtin_fabsf(noi.x) < __builtin_inff())) { finv.x = 0.0f; noi.x = __builtin_nanf(""); }
     if (!(__builtin_fabsf(noi.y) < __builtin_inff())) { finv.y = 0.0f; noi.y = __builtin_nanf(""); }
     if (!(__builtin_fabsf(noi.z) < __builtin_inff())) { finv.z = 0.0f; noi.z = __builtin_nanf(""); }
-#ifdef RRT_PHASE_PROFILE
-    unsigned long long prof_filter = 0, prof_items = 0, prof_groups = 0, prof_phases = 0;
-#endif
+    SiftProbe probe;
     const cv4p cnodes = sc.c_nodes();
     const cv4p cpairs = sc.c_pairs();
     uint32_t sp = 0, cur = 0;
@@ -614,19 +604,17 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                     else items[n_items + rank] = ((leaf_first + k) << 6) | lane;
                 }
                 n_items += (uint32_t)__popcll(bal);
-                RRT_COUNT(prof_filter, 1);
+                probe.pair_tested();
                 if (n_items > CAP - 64u) {
-                    RRT_COUNT(prof_items, n_items);
-                    RRT_COUNT(prof_groups, (n_items + 63u) / 64u);
+                    probe.flushed(n_items);
                     sift_flush<FEAT, HARVEST, CAP>(sc, r, t_min, t_max, key, depth, items, n_items, best);
                     n_items = 0;
                 }
             }
             todo &= ~RRT_BALLOT(mine);
         }
-        RRT_COUNT(prof_items, n_items);
-        RRT_COUNT(prof_groups, (n_items + 63u) / 64u);
-        RRT_COUNT(prof_phases, 1);
+        probe.flushed(n_items);
+        probe.phase_done();
         sift_flush<FEAT, HARVEST, CAP>(sc, r, t_min, t_max, key, depth, items, n_items, best);
         if (pending) {
             if (HARVEST)
@@ -646,14 +634,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             }
         }
     }
-#ifdef RRT_PHASE_PROFILE
-    if (lane == 0) {  // wave-level counts
-        atomicAdd(&g_prof[4], prof_filter);
-        atomicAdd(&g_prof[5], prof_items);
-        atomicAdd(&g_prof[6], prof_groups);
-        atomicAdd(&g_prof[7], prof_phases);
-    }
-#endif
+    probe.store(lane);
     if (WANT_UV && (FEAT & (F_TEX | F_BUMP)) && h.slot >= 0) {
         // Triangle::get_hit_properties recomputes the barycentrics from the ray (shape.rs:384-400); so does this path
         // (callers that shade later, from a stored hit, pass WANT_UV = false and do this themselves)
