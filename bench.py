@@ -220,7 +220,7 @@ def main():
         nominal = rays_per_launch * bytes_per_ray / k_s / 1e9
         step_ms = elapsed / max(args.steps, 1) * 1e3
         pmc = pmc_record("c5" if c5 else "headline")
-        roofline = {"kernel": "k_trace_stream" if c5 else "k_trace", "kernel_ms": k_s * 1e3, "launches_per_step": launches / max(args.steps, 1),
+        roofline = {"kernel": "k_trace_stream" if c5 else "k_trace_pool", "kernel_ms": k_s * 1e3, "launches_per_step": launches / max(args.steps, 1),
                     "rays_per_launch": rays_per_launch, "accumulate_ms_per_step": accumulate_ms / max(args.steps, 1),
                     "render_ms_per_step": float(np.mean(render_ms)) if render_ms else None,
                     "nominal_hbm_achieved": nominal, "nominal_hbm_frac": nominal / HBM_PEAK_GBS, "bytes_per_ray": bytes_per_ray, "traffic": None}

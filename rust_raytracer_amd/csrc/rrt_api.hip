@@ -1178,7 +1178,7 @@ int rrt_intersect_batch_device(rrt_scene* s, const float* d_o, const float* d_d,
         const dim3 grid((unsigned)((n + run - 1) / run));
         // deep trees: the reference's test alone IS exhaustive (leaves are tested whole)
         const int mode = s->clean ? kAabbClean : (aabb_mode != RRT_AABB_TIGHT ? (int)RRT_AABB_REFERENCE : (int)RRT_AABB_TIGHT);
-        HIP_TRY(launch_intersect_stream(mode, grid, lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, run, 24u, d_prim, d_t));
+        HIP_TRY(launch_intersect_stream(mode, grid, lds, st, s->d, d_o, d_d, n, t_min, t_max, seed, lds_entries, run, s->clean ? 2u : 24u, d_prim, d_t));
     } else {
         const dim3 grid((unsigned)((n + kBlock - 1) / kBlock));
         const size_t lds = (size_t)kBlock * s->stack_depth * sizeof(uint32_t) + (size_t)(kBlock / 64) * kSiftBytesPerWave;
@@ -1307,8 +1307,13 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
     }
     ta.stack_depth = s->deep && s->stack_depth > s->lds_stack ? s->lds_stack : s->stack_depth;
     const size_t lds = (size_t)kTraceBlock * ta.stack_depth * sizeof(uint32_t) + (s->deep ? kCoopBytesPerWave : kSiftBytesPerWave + kHarvestBytesPerWave);
-    ta.coop_lanes = 24;   // paused / finished lanes that trigger a leaf / shading phase; measured on a 500 000-triangle mesh with a
-    ta.shade_lanes = 16;  // clean tree, 1024x1024 @ 64 spp: 8/16 -> 172 ms, 16/16 -> 147 ms, 24/16 -> 140 ms, 32/16 -> 143 ms, 16/8 -> 154 ms, 16/32 -> 152 ms
+    // Lanes at a leaf / finished lanes that trigger a leaf / shading phase.  Reference trees (a lane waits at its leaf), measured on a
+    // 500 000-triangle mesh, 1024x1024 @ 64 spp: 8/16 -> 172 ms, 16/16 -> 147 ms, 24/16 -> 140 ms, 32/16 -> 143 ms, 16/8 -> 154 ms,
+    // 16/32 -> 152 ms.  Clean trees (a lane keeps its leaf and walks on, see walk_step): the sooner a held leaf is tested the fewer
+    // nodes are visited with a stale closest distance; 500 000 triangles 1024x1024 @ 16 / 10 M triangles 3840x2160 @ 8:
+    // 2 -> 37.2 / 267.6 ms, 8 -> 38.0 / 274.9, 24 -> 39.6 / 280.4, 40 -> 42.9 / 301.7 (without holding: 40.0 / 286.1).
+    ta.coop_lanes = s->clean ? 2 : 24;
+    ta.shade_lanes = 16;
     hipStream_t st = (hipStream_t)stream;
     // compiled variants: plain (triangles + spheres, constant textures), textured (+ textures, bump maps), full (+ media)
     constexpr uint32_t kPlain = F_SPHERE, kTextured = F_SPHERE | F_TEX | F_BUMP;

@@ -107,18 +107,25 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
                 walk_step<AABB_MODE>(sc, w, r, RRT_T_MIN, stack);
                 if (w.pending) {
                     st = LEAF;
-                    probe.leaf_reached(w.n_pairs);
-                } else if (!w.running) st = READY;
+                    probe.leaf_reached(AABB_MODE == kAabbClean ? link_pairs(w.cur) : w.n_pairs);
+                } else if (!w.running) st = (AABB_MODE == kAabbClean && w.held != 0u) ? LEAF : READY;  // (a held leaf is still to be tested)
             }
         }
         probe.walked(lane);
-        const unsigned long long at_leaf = RRT_BALLOT(st == LEAF);
+        // (clean trees: lanes that hold a leaf count, whether they still walk or not)
+        const unsigned long long at_leaf = RRT_BALLOT(AABB_MODE == kAabbClean ? w.held != 0u : st == LEAF);
         if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= ta.coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
             probe.leaf_phase_begins(lane);
-            coop_leaves<FEAT, AABB_MODE == kAabbClean>(sc, r, RRT_T_MIN, g, depth, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
-            if (st == LEAF) {
-                walk_resume(w, stack);
-                st = w.running ? WALK : READY;
+            if (AABB_MODE == kAabbClean) {  // every lane's held leaf, see walk_step
+                const bool has = w.held != 0u;
+                coop_leaves<FEAT, true>(sc, r, RRT_T_MIN, g, depth, has, link_first_pair(w.held), link_pairs(w.held), w.h, coop);
+                if (has) st = walk_after_held(w, stack) ? (w.running ? WALK : LEAF) : READY;
+            } else {
+                coop_leaves<FEAT, false>(sc, r, RRT_T_MIN, g, depth, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
+                if (st == LEAF) {
+                    walk_resume(w, stack);
+                    st = w.running ? WALK : READY;
+                }
             }
             probe.leaf_phase_done();
         }
@@ -192,15 +199,21 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect_stream(DScene sc, con
             if (st == WALK) {
                 walk_step<AABB_MODE>(sc, w, r, t_min, stack);
                 if (w.pending) st = LEAF;
-                else if (!w.running) st = READY;
+                else if (!w.running) st = (AABB_MODE == kAabbClean && w.held != 0u) ? LEAF : READY;
             }
         }
-        const unsigned long long at_leaf = RRT_BALLOT(st == LEAF);
+        const unsigned long long at_leaf = RRT_BALLOT(AABB_MODE == kAabbClean ? w.held != 0u : st == LEAF);
         if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
-            coop_leaves<F_ALL, AABB_MODE == kAabbClean>(sc, r, t_min, g, 0, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
-            if (st == LEAF) {
-                walk_resume(w, stack);
-                st = w.running ? WALK : READY;
+            if (AABB_MODE == kAabbClean) {
+                const bool has = w.held != 0u;
+                coop_leaves<F_ALL, true>(sc, r, t_min, g, 0, has, link_first_pair(w.held), link_pairs(w.held), w.h, coop);
+                if (has) st = walk_after_held(w, stack) ? (w.running ? WALK : LEAF) : READY;
+            } else {
+                coop_leaves<F_ALL, false>(sc, r, t_min, g, 0, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
+                if (st == LEAF) {
+                    walk_resume(w, stack);
+                    st = w.running ? WALK : READY;
+                }
             }
         }
     }

@@ -278,6 +278,7 @@ struct Walk {
     bool running;  // has a node to visit
     bool pending;  // stands at a leaf (first_pair, n_pairs) that the next cooperative phase tests
     uint32_t first_pair, n_pairs;
+    uint32_t held;  // clean trees: the link of a leaf reached but not yet tested (0: none), see walk_step
     f3 inv;
     uint32_t down;  // bit c: the ray runs towards smaller coordinates on axis c
     Hit h;
@@ -307,6 +308,7 @@ RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, fl
     w.cur = sc.root_link;  // 0 for the reference's trees
     w.pending = false;
     w.first_pair = w.n_pairs = 0;
+    w.held = 0u;
     w.running = active && sc.n_nodes != 0 && w.cur != kLinkNone;  // kLinkNone: a clean tree whose only leaf is empty
     w.inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     w.down = (w.inv.x < 0.0f ? 1u : 0u) | (w.inv.y < 0.0f ? 2u : 0u) | (w.inv.z < 0.0f ? 4u : 0u);
@@ -320,11 +322,20 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, con
         // One 128-byte fetch brings the boxes of up to four children: only children the ray meets are ever fetched themselves,
         // and leaves are not fetched at all (their pair range sits in the link).  Children are visited nearest entry first;
         // the result does not depend on the order (ties go by scene order, see coop_leaves).
+        // A lane that reaches a leaf does not stop for it: it keeps the leaf's link ("held") and walks on, and stops only at the
+        // NEXT leaf (or when its walk is over).  The wave's cooperative phases test the held leaves of ALL lanes, walking or not,
+        // so a phase serves more lanes and fewer lanes stand idle waiting for one.  The nodes visited meanwhile are culled with
+        // the closest distance known before the held leaf's test - a few more visits, the same result: in a clean tree the
+        // answer does not depend on the order of the tests (nearest hit, ties by scene order).
         if (w.cur & kLinkLeaf) {
-            w.pending = true;
+            if (w.held == 0u) {
+                w.held = w.cur;
+                if (w.sp == 0) w.running = false;
+                else w.cur = stack_pop(stack, w.sp);
+                return;
+            }
+            w.pending = true;  // (w.cur keeps the second leaf's link)
             w.running = false;
-            w.first_pair = w.cur & 0x0fffffffu;
-            w.n_pairs = ((w.cur >> 28) & 7u) + 1u;
             return;
         }
         const uint32_t base = 8u * w.cur;
@@ -390,6 +401,23 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, con
     } else {
         w.cur = stack_pop(stack, w.sp);
     }
+}
+// Clean trees: the pair range of a leaf link.
+RRT_DEV uint32_t link_first_pair(uint32_t link) { return link & 0x0fffffffu; }
+RRT_DEV uint32_t link_pairs(uint32_t link) { return ((link >> 28) & 7u) + 1u; }
+// Clean trees, after a cooperative phase that tested this lane's held leaf: a lane that stood at a second leaf now holds
+// that one and walks on.  Returns false when nothing is left to do for the query (no node to visit, no leaf held).
+RRT_DEV bool walk_after_held(Walk& w, const WalkStack& stack) {
+    w.held = 0u;
+    if (w.pending) {
+        w.held = w.cur;
+        w.pending = false;
+        if (w.sp != 0) {
+            w.cur = stack_pop(stack, w.sp);
+            w.running = true;
+        }
+    }
+    return w.running || w.held != 0u;
 }
 // After the cooperative phase that tested this lane's leaf.
 RRT_DEV void walk_resume(Walk& w, const WalkStack& stack) {

@@ -28,6 +28,7 @@ __global__ __launch_bounds__(64) void k(unsigned long long* ticks, const float* 
     v2f ss = {s0, s0};
     unsigned long long t0, t1, r0, r1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memrealtime %0\n s_memtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(r0), "=s"(t0)::"memory");
+    asm volatile("s_mov_b32 vcc_lo, 0x55555555\n s_mov_b32 vcc_hi, 0x55555555" ::: "vcc");  // a defined mask for the select
     for (int i = 0; i < iters; ++i) {
         if (KIND == MUL_VV) { BODY("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8") }
         if (KIND == FMA_VVV) { BODY("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8") }
@@ -46,8 +47,10 @@ __global__ __launch_bounds__(64) void k(unsigned long long* ticks, const float* 
     }
     asm volatile("s_memtime %0\n s_memrealtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(t1), "=s"(r1)::"memory");
     if (threadIdx.x == 0) {  // (a vector store: one record per wave)
-        ticks[2 * blockIdx.x] = t1 - t0;
-        ticks[2 * blockIdx.x + 1] = r1 - r0;
+        ticks[4 * blockIdx.x] = t1 - t0;
+        ticks[4 * blockIdx.x + 1] = r1 - r0;
+        ticks[4 * blockIdx.x + 2] = r0;  // absolute 100 MHz times: when the whole grid began and ended
+        ticks[4 * blockIdx.x + 3] = r1;
     }
     if (a0 + a1 + a2 + a3 + p0.x + p1.x + p2.x + p3.x == 12345.678f) ticks[0] = 0;  // keeps the accumulators alive
 }
@@ -62,17 +65,23 @@ static void run(unsigned long long* d_ticks, float* d_in, int cus) {
         hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, d_ticks, d_in, 8, 1.0f);
         hipLaunchKernelGGL(k<KIND>, dim3(blocks), dim3(64), 0, 0, d_ticks, d_in, iters, 1.0f);
         (void)hipDeviceSynchronize();
-        std::vector<unsigned long long> h(2 * blocks);
+        std::vector<unsigned long long> h(4 * blocks);
         (void)hipMemcpy(h.data(), d_ticks, h.size() * 8, hipMemcpyDeviceToHost);
         std::vector<double> cyc(blocks), mhz(blocks);
+        unsigned long long first = ~0ull, last = 0;
         for (int b = 0; b < blocks; ++b) {
-            cyc[b] = (double)h[2 * b];
-            mhz[b] = h[2 * b + 1] ? 100.0 * (double)h[2 * b] / (double)h[2 * b + 1] : 0.0;
+            cyc[b] = (double)h[4 * b];
+            mhz[b] = h[4 * b + 1] ? 100.0 * (double)h[4 * b] / (double)h[4 * b + 1] : 0.0;
+            first = std::min(first, h[4 * b + 2]);
+            last = std::max(last, h[4 * b + 3]);
         }
         std::nth_element(cyc.begin(), cyc.begin() + blocks / 2, cyc.end());
         std::nth_element(mhz.begin(), mhz.begin() + blocks / 2, mhz.end());
         // a SIMD issues for its `wps` waves in turn: the cost of one instruction is the wave's elapsed ticks / (instr x wps)
-        std::printf("  %dw %5.2f (%4.0f MHz)", wps, cyc[blocks / 2] / (instr * wps), mhz[blocks / 2]);
+        // and for the chip as a whole: the span from the first wave's start to the last wave's end, in shader-clock cycles, times the
+        // SIMDs, over all instructions issued - equal to the per-wave figure when all waves really ran side by side
+        const double span_cycles = (double)(last - first) / 100.0 * mhz[blocks / 2];
+        std::printf("  %dw %5.2f|%5.2f (%4.0f MHz)", wps, cyc[blocks / 2] / (instr * wps), span_cycles * (cus * 4.0) / (instr * blocks), mhz[blocks / 2]);
     }
     std::printf("\n");
 }
@@ -82,11 +91,12 @@ int main() {
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0);
     unsigned long long* d_ticks;
     float* d_in;
-    (void)hipMalloc(&d_ticks, (size_t)cus * 4 * 8 * 2 * 8);
+    (void)hipMalloc(&d_ticks, (size_t)cus * 4 * 8 * 4 * 8);
     (void)hipMalloc(&d_in, 64 * 4);
     (void)hipMemset(d_in, 0, 64 * 4);
     std::printf("%d compute units; median over waves of: s_memtime ticks per wave64 instruction per SIMD with 1/2/4/8 waves per SIMD\n"
-                "(in brackets: s_memtime ticks per microsecond of s_memrealtime = the rate of that counter)\n", cus);
+                "after the bar: the same from the whole grid's span (first start to last end); in brackets: s_memtime ticks per microsecond of\n"
+                "s_memrealtime = the rate of that counter\n", cus);
     run<MUL_VV>(d_ticks, d_in, cus);
     run<FMA_VVV>(d_ticks, d_in, cus);
     run<MUL_VS>(d_ticks, d_in, cus);
