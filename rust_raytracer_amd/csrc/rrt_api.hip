@@ -1333,14 +1333,19 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
         }
         ta.n_samples = plan.spp - done < per_pass ? plan.spp - done : (uint32_t)per_pass;
         ta.first_sample = plan.ta.first_sample + done;
-        // A frame of few wave items ends in a tail of half-empty compute units (and cannot balance long and short items):
-        // smaller sample pools until the pass has ten items per wave place of the chip (256 compute units x 16).  Pools below
-        // 16 samples per pixel cost more in ramp-up and drain than they balance, except on deep trees, where an item is long
-        // (thousands of dependent node fetches).  Measured: Cornell_Box 512x512@64 4.77 -> 3.53 ms, Materials 640x360@64 6.20 ->
-        // 2.41 ms, headline scene 1024x1024@128 39.9 -> 38.1 ms; 500 000 triangles 1024x1024@64: pools of 64 / 32 / 16 / 8 -> 197
-        // / 161 / 147 / 150 ms; 10 M triangles 1024x576@64: 64 -> 640 ms, 8 -> 252 ms, 4 -> 265 ms.
-        constexpr uint64_t want = 40960;
-        const uint32_t least = s->deep ? 4u : 16u;
+        // Wave items are (8x8 pixels) x `chunk` samples, handed out to persistent waves through an atomic counter.  The launch ends
+        // when the last item does, so an item must be short against the launch: chunks are halved until the pass has enough items.
+        // Shallow trees (k_trace_pool; an item of 64 samples per pixel takes ~0.2 ms): 163 840 items, chunks of 4 at least -
+        // Cornell_Box 512x512@64 2.97 -> 2.62 ms, headline scene 1024x1024@128 29.6 -> 28.2 ms, Materials 1920x1080@64 12.4 -> 12.5 ms
+        // (655 360 items: Materials 13.7 ms, Globe 3840x2160@32 8.4 -> 13.3 ms: the per-item work then shows).  Deep trees
+        // (k_trace_stream; a 10 M-triangle mesh at 3840x2160@16 spends 46 ms on an item of 16 samples per pixel): 655 360 items,
+        // chunks down to 1 - 40 960 / 163 840 / 655 360 / 2 621 440 items: 474.7 / 443.0 / 437.1 / 457.4 ms there, 101.5 / 92.4 / 90.1 /
+        // 90.6 ms on 500 000 triangles at 1024x1024@64.
+        // (k_trace, one block per item: 40 960 items, chunks of 16 at least - shorter blocks cost more in ramp-up and drain than they balance)
+        const bool exhaustive = p->aabb_mode == RRT_AABB_EXHAUSTIVE && !s->deep;
+        const bool pooled = !exhaustive && s->pooling && !s->deep && ta.max_depth <= kPoolMaxDepth && ta.n_samples <= kPoolMaxSamples && s->d.n_lights <= kPoolMaxLights;
+        const uint64_t want = s->deep ? 655360 : (pooled ? 163840 : 40960);
+        const uint32_t least = s->deep ? 1u : (pooled ? 4u : 16u);
         ta.chunk = kChunk;
         while (ta.chunk > least && (uint64_t)((ta.n_samples + ta.chunk - 1) / ta.chunk) * ta.n_t8 < want) ta.chunk /= 2u;
         const uint64_t items = (uint64_t)((ta.n_samples + ta.chunk - 1) / ta.chunk) * ta.n_t8;
@@ -1348,10 +1353,10 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
         const dim3 grid((unsigned)items);
         float* const pass_slab = static_staging ? slab : s->slab;
         // shallow trees: the pooled schedule (k_trace_pool) - a persistent grid that hands the items out itself
-        if (p->aabb_mode == RRT_AABB_EXHAUSTIVE && !s->deep) {
+        if (exhaustive) {
             // the yardstick mode on a shallow tree: one kernel variant (every feature, one path per lane); speed is not its point
             hipLaunchKernelGGL((k_trace<kAabbExhaustive, F_ALL>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt);
-        } else if (s->pooling && !s->deep && ta.max_depth <= kPoolMaxDepth && ta.n_samples <= kPoolMaxSamples && s->d.n_lights <= kPoolMaxLights) {
+        } else if (pooled) {
             ta.n_items = (uint32_t)items;
             const dim3 pgrid((unsigned)(items < s->wave_places ? items : s->wave_places));
             if (s->harvest) ta.stack_depth = 0;  // a single leaf: the walk never pushes
@@ -1383,7 +1388,10 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
     } while (0)
         if (s->deep) {  // (clean trees are deep by definition)
             const int mode = s->clean ? kAabbClean : (p->aabb_mode != RRT_AABB_TIGHT ? (int)RRT_AABB_REFERENCE : (int)RRT_AABB_TIGHT);
-            HIP_TRY(launch_trace_stream(mode, (need & ~kPlain) != 0, grid, lds, st, s->d, ta, pass_slab, cnt));
+            ta.n_items = (uint32_t)items;
+            const dim3 sgrid((unsigned)(items < s->wave_places ? items : s->wave_places));  // one round of the chip, see k_trace_stream
+            HIP_TRY(hipMemsetAsync(s->d_items, 0, sizeof(uint32_t), st));
+            HIP_TRY(launch_trace_stream(mode, (need & ~kPlain) != 0, sgrid, lds, st, s->d, ta, pass_slab, cnt, s->d_items));
         } else if (p->aabb_mode != RRT_AABB_TIGHT) RRT_PICK(RRT_AABB_REFERENCE);
         else RRT_PICK(RRT_AABB_TIGHT);
         }

@@ -44,9 +44,10 @@ struct TraceArgs {
 #endif
 
 // k_trace_stream<mode, features>: mode RRT_AABB_TIGHT / RRT_AABB_REFERENCE / kAabbClean, every_feature false = triangles and spheres
-// with constant textures.  Returns hipGetLastError() of the launch.
+// with constant textures.  The grid is persistent: ta.n_items wave items are handed out through *item_counter, which must be zero
+// when the kernel starts.  Returns hipGetLastError() of the launch.
 hipError_t launch_trace_stream(int mode, bool every_feature, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const TraceArgs& ta, float* slab,
-                               unsigned long long* counters);
+                               unsigned long long* counters, uint32_t* item_counter);
 // k_intersect_stream<mode>
 hipError_t launch_intersect_stream(int mode, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const float* o, const float* d, size_t n, float t_min,
                                    float t_max, uint32_t seed, uint32_t lds_entries, uint32_t run, uint32_t coop_lanes, int* prim, float* t_hit);

@@ -17,28 +17,22 @@ namespace {
 // a shading phase (shade, store, draw the next sample, make the camera ray) when enough lanes are READY or FRESH.  A lane
 // that finishes its query early is shaded and sent walking again while its neighbours are still in their queries.
 template <int AABB_MODE, uint32_t FEAT>
-__global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stream(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters) {
+__global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stream(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters,
+                                                                                   uint32_t* __restrict__ item_counter) {
     extern __shared__ uint32_t lds_stack[];
     const uint32_t lane = threadIdx.x;
-    // Workgroups go to the eight XCDs (each with an L2 of its own) round-robin by number.  Renumbered in groups of 128, the
-    // sixteen 8x8 tiles of one 32x32 tile land on ONE XCD, neighbouring 32x32 tiles on neighbouring XCDs (balance stays fine-grained).
-    uint32_t item = blockIdx.x;
-    if (item < (gridDim.x & ~127u)) item = (((item >> 7) * 8u + (item & 7u)) << 4) | ((item >> 3) & 15u);
-    const uint32_t chunk = item / ta.n_t8, j = item % ta.n_t8;
-    const uint32_t tile32 = ta.tile_index + (j >> 4) * ta.tile_count;
-    const uint32_t x0 = (tile32 % ta.tiles_x) * 32u + ((j & 3u) << 3);
-    const uint32_t y0 = (tile32 / ta.tiles_x) * 32u + (((j >> 2) & 3u) << 3);
-    const uint32_t s0 = chunk * ta.chunk;
-    const uint32_t ns = ta.n_samples - s0 < ta.chunk ? ta.n_samples - s0 : ta.chunk;
-    const uint32_t pool = ns * 64u;
+    // Waves are persistent: the grid is one round of the chip, and a wave whose item (a tile of 8x8 pixels x `chunk` samples) has no
+    // undrawn sample left takes the next item from an atomic counter, so lanes never stand idle while their neighbours finish the
+    // item's last paths, and the launch's tail is one path long.
+    uint32_t x0 = 0, y0 = 0, s0 = 0, pool = 0;  // the current item (wave-uniform)
+    bool exhausted = false;                     // no items left in the pass
     uint32_t beyond[kMaxStackDepth];  // private memory; sized for any split of the stack the host may choose
     const WalkStack stack = {lds_stack + lane, kTraceBlock, ta.stack_depth, beyond};
     unsigned char* coop = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
     enum : uint32_t { DEAD = 0, FRESH = 1, WALK = 2, LEAF = 3, READY = 4 };
 
-    uint32_t next = 64u;  // next undrawn pool index (wave-uniform)
-    uint32_t idx = lane;
-    uint32_t st = idx < pool ? FRESH : DEAD;
+    uint32_t next = 0u;  // next undrawn sample of the item (wave-uniform)
+    uint32_t st = DEAD;  // DEAD: the lane has no path and takes the next undrawn sample
     unsigned long long rays = 0, paths = 0;
     uint32_t px = 0, py = 0, smp = 0, depth = 0;
     Ray r;
@@ -50,10 +44,47 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
     walk_begin(sc, w, false, r, RRT_T_MAX);
     StreamProbe probe;
     for (;;) {
+        // ---- lanes without a path draw the next samples (≙ main.rs:150-157: the queue of (pixel, sample) work items)
+        const unsigned long long idle = RRT_BALLOT(st == DEAD);
+        if (idle != 0ull && !exhausted) {
+            if (next >= pool) {
+                uint32_t item = 0;
+                if (lane == 0) item = atomicAdd(item_counter, 1u);
+                item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+                if (item >= ta.n_items) {
+                    exhausted = true;
+                } else {
+                    // Renumbered in groups of 128, the sixteen 8x8 tiles of one 32x32 tile are consecutive items: the waves that
+                    // work on neighbouring pixels at the same time share the tree's nodes in the caches.
+                    if (item < (ta.n_items & ~127u)) item = (((item >> 7) * 8u + (item & 7u)) << 4) | ((item >> 3) & 15u);
+                    const uint32_t chunk = item / ta.n_t8, j = item % ta.n_t8;
+                    const uint32_t tile32 = ta.tile_index + (j >> 4) * ta.tile_count;
+                    x0 = (tile32 % ta.tiles_x) * 32u + ((j & 3u) << 3);
+                    y0 = (tile32 / ta.tiles_x) * 32u + (((j >> 2) & 3u) << 3);
+                    s0 = chunk * ta.chunk;
+                    pool = (ta.n_samples - s0 < ta.chunk ? ta.n_samples - s0 : ta.chunk) * 64u;
+                    next = 0;
+                }
+            }
+            if (!exhausted) {
+                const uint32_t idx = next + __builtin_amdgcn_mbcnt_hi((uint32_t)(idle >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)idle, 0u));
+                if (st == DEAD && idx < pool) {  // (lanes beyond the item's end are served from the next item, next turn)
+                    px = x0 + (idx & 7u);
+                    py = y0 + ((idx >> 3) & 7u);
+                    smp = s0 + (idx >> 6);
+                    st = FRESH;
+                }
+                const uint32_t drawn = (uint32_t)__popcll(idle);
+                next = pool - next < drawn ? pool : next + drawn;
+            }
+        }
         const unsigned long long walking = RRT_BALLOT(st == WALK), paused = RRT_BALLOT(st == LEAF), waiting = RRT_BALLOT(st == READY || st == FRESH);
-        if ((walking | paused | waiting) == 0ull) break;
+        if ((walking | paused | waiting) == 0ull) {
+            if (exhausted) break;
+            continue;  // every lane was beyond the item's end: next item
+        }
         if (waiting != 0ull && ((uint32_t)__popcll(waiting) >= ta.shade_lanes || (walking | paused) == 0ull)) {
-            bool done = false;  // this lane needs a new sample
+            bool done = false;  // this lane's path has ended
             bool launch = false;  // this lane has a new ray to trace
             if (st == READY) {
                 ++rays;
@@ -70,9 +101,6 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
                     launch = true;
                 }
             } else if (st == FRESH) {
-                px = x0 + (idx & 7u);
-                py = y0 + ((idx >> 3) & 7u);
-                smp = s0 + (idx >> 6);
                 if (px < ta.W && py < ta.H) {
                     g = rng_seed(ta.seed, py * ta.W + px, ta.first_sample + smp);
                     r = camera_ray(sc.cam, px, py, ta.W, ta.H, g);
@@ -88,13 +116,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
                 walk_begin(sc, w, true, r, RRT_T_MAX);
                 st = w.running ? WALK : READY;  // an empty scene answers at once
             }
-            const unsigned long long finished = RRT_BALLOT(done);
-            if (done) {
-                const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(finished >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)finished, 0u));
-                idx = next + rank;
-                st = idx < pool ? FRESH : DEAD;
-            }
-            next += (uint32_t)__popcll(finished);
+            if (done) st = DEAD;
             probe.shaded();
             continue;
         }
@@ -224,12 +246,12 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect_stream(DScene sc, con
 namespace rrt {
 
 hipError_t launch_trace_stream(int mode, bool every_feature, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const TraceArgs& ta, float* slab,
-                               unsigned long long* counters) {
+                               unsigned long long* counters, uint32_t* item_counter) {
     constexpr uint32_t kPlain = F_SPHERE;
 #define RRT_GO(MODE)                                                                                                                       \
     do {                                                                                                                                   \
-        if (every_feature) hipLaunchKernelGGL((k_trace_stream<MODE, F_ALL>), grid, dim3(kTraceBlock), lds, st, sc, ta, slab, counters);   \
-        else hipLaunchKernelGGL((k_trace_stream<MODE, kPlain>), grid, dim3(kTraceBlock), lds, st, sc, ta, slab, counters);                \
+        if (every_feature) hipLaunchKernelGGL((k_trace_stream<MODE, F_ALL>), grid, dim3(kTraceBlock), lds, st, sc, ta, slab, counters, item_counter);   \
+        else hipLaunchKernelGGL((k_trace_stream<MODE, kPlain>), grid, dim3(kTraceBlock), lds, st, sc, ta, slab, counters, item_counter);                \
     } while (0)
     if (mode == kAabbClean) RRT_GO(kAabbClean);
     else if (mode == RRT_AABB_REFERENCE) RRT_GO(RRT_AABB_REFERENCE);
