@@ -1314,6 +1314,11 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
     // 2 -> 37.2 / 267.6 ms, 8 -> 38.0 / 274.9, 24 -> 39.6 / 280.4, 40 -> 42.9 / 301.7 (without holding: 40.0 / 286.1).
     ta.coop_lanes = s->clean ? 2 : 24;
     ta.shade_lanes = 16;
+    // Node steps per turn of k_trace_stream's loop (the bookkeeping of a turn - the ballots, the phase decisions - costs a quarter of a
+    // node step).  10 M triangles at 3840x2160@8 / 500 000 triangles at 1024x1024@32, persistent grid: 2 -> 275.9 / 57.4 ms, 3 -> 246.8 /
+    // 50.7, 4 -> 241.2 / 48.6, 6 -> 233.4 / 48.6, 8 -> 231.1 / 51.0.  (Shading at 8 / 16 / 24 / 32 finished lanes: 244.6 / 241.2 / 237.6 /
+    // 243.5 and 49.4 / 48.6 / 49.6 / 52.5 ms.)
+    ta.walk_steps = 6;
     hipStream_t st = (hipStream_t)stream;
     // compiled variants: plain (triangles + spheres, constant textures), textured (+ textures, bump maps), full (+ media)
     constexpr uint32_t kPlain = F_SPHERE, kTextured = F_SPHERE | F_TEX | F_BUMP;

@@ -15,8 +15,7 @@ constexpr int kTraceBlock = 64;          // k_trace: one wave per block, the uni
 #define RRT_CHUNK 64
 #endif
 constexpr uint32_t kChunk = RRT_CHUNK;   // samples of each pixel handled by one wave item
-constexpr int kWalkSteps = 4;            // k_trace_stream: node steps per turn of the wave's loop (1 / 2 / 3 / 4 / 6 measured on a 500 000-triangle
-                                         // mesh: 141.6 / 134.6 / 131.7 / 132.9 / 129.7 ms; 10 M triangles at 4K: 603 / 579 / 566 / 560 / 565 ms)
+constexpr int kWalkSteps = 4;            // k_intersect_stream: node steps per turn of the wave's loop (TraceArgs::walk_steps for k_trace_stream)
 constexpr uint32_t kMaxStackDepth = 64;  // traversal stack: entries per lane
 constexpr uint32_t kLdsStackEntries = 32;  // k_trace_stream keeps this many of them in LDS (10 KB per wave with the cooperative area: 16 waves
                                            // per compute unit), the rest in private memory
@@ -36,6 +35,7 @@ struct TraceArgs {
     uint32_t stack_depth;                                // LDS stack entries per lane (the cooperative-leaf area follows the stack)
     uint32_t chunk;                                      // samples of each pixel handled by one wave item (divides kChunk)
     uint32_t coop_lanes, shade_lanes;                    // k_trace_stream: paused / finished lanes that trigger a leaf / shading phase
+    uint32_t walk_steps;                                 // k_trace_stream: node steps per turn of the wave's loop
     uint32_t n_items;                                    // k_trace_pool: (tile, chunk) items of the pass, handed out through an atomic counter
 };
 

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
         // several node steps before the wave looks at its lanes' states again: the bookkeeping of a turn (five ballots, the
         // phase decisions) costs a quarter of a node step
 #pragma unroll 1
-        for (int rep = 0; rep < kWalkSteps; ++rep) {
+        for (uint32_t rep = 0; rep < ta.walk_steps; ++rep) {
             if (st == WALK) {
                 probe.node_visited();
                 walk_step<AABB_MODE>(sc, w, r, RRT_T_MIN, stack);
