@@ -877,12 +877,15 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         }
         const std::vector<float> tb = tight_boxes(desc);
         if (clean) {
-            // Inner nodes only, 128 bytes each, with up to FOUR children (see walk_step): quads 0..5 hold the children's
-            // primitive boxes plane by plane (lo.x of the four children, hi.x, lo.y, hi.y, lo.z, hi.z), quad 6 their links: an
-            // inner node's number, kLinkLeaf | (pairs - 1) << 28 | first pair, or kLinkNone for an unused place.  A node
-            // starts from the sweep's two children and replaces the child with the largest box by that child's own two
-            // until it has four; a leaf of more than 8 pair records (shapes the sweep would not separate) is split by
-            // halving its range.
+            // Inner nodes only, 64 bytes each, with up to FOUR children (see walk_step).  The children's primitive boxes are stored
+            // as bytes on a grid of the node's own: dwords 0..2 the grid's origin (the low corner of the children's common box),
+            // dword 3 the grid steps as three power-of-two exponents, dwords 4..9 the planes (lo.x of the four children, hi.x,
+            // lo.y, hi.y, lo.z, hi.z; lows rounded down, highs up, so a stored box contains the exact one), dwords 10..13 the
+            // links: an inner node's number, kLinkLeaf | (pairs - 1) << 28 | first pair, or kLinkNone for an unused place.
+            // Half the bytes of float planes and, what counts for a walk whose lanes all sit in different nodes, four 16-byte
+            // loads per visit instead of seven.  A node starts from the sweep's two children and replaces the child with the
+            // largest box by that child's own two until it has four; a leaf of more than 8 pair records (shapes the sweep would
+            // not separate) is split by halving its range.
             std::vector<float> rec;
             auto pair_range_box = [&](uint32_t first, uint32_t count, float* b) {  // pair boxes are stored (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z)
                 const float inf = std::numeric_limits<float>::infinity();
@@ -923,12 +926,10 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                 }
             };
             auto new_inner = [&]() {
-                const float inf = std::numeric_limits<float>::infinity();
                 const size_t at = rec.size();
-                rec.resize(at + 32, 0.0f);
-                for (int k = 0; k < 24; ++k) rec[at + k] = inf;  // a box no ray meets
-                for (int k = 24; k < 28; ++k) rec[at + k] = put_u(kLinkNone);
-                return (uint32_t)(at / 32);
+                rec.resize(at + 16, 0.0f);
+                for (int k = 10; k < 14; ++k) rec[at + k] = put_u(kLinkNone);
+                return (uint32_t)(at / 16);
             };
             if ((uint64_t)pairs.size() / (4 * kPairQuads) >= 0x0fffffffull)  // keeps every leaf link apart from kLinkNone
                 return rrt_set_error(RRT_ERR_LIMIT, "clean tree: more than 2^28 - 2 pair records");
@@ -963,18 +964,51 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                 }
                 const uint32_t pending_here = it.above + n_kids - 1u;  // the walk pushes every child it meets but the nearest
                 if (pending_here > clean_depth) clean_depth = pending_here;
+                // the node's grid: origin = low corner of the children's common box, step 2^e per axis with 255 steps spanning it
+                float lo[3], hi[3];
+                uint32_t expo[3], planes[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+                for (int c = 0; c < 3; ++c) {
+                    lo[c] = kids[0].box[c];
+                    hi[c] = kids[0].box[4 + c];
+                    for (uint32_t k = 1; k < n_kids; ++k) {
+                        lo[c] = std::fmin(lo[c], kids[k].box[c]);
+                        hi[c] = std::fmax(hi[c], kids[k].box[4 + c]);
+                    }
+                    int e = 0;
+                    const double span = (double)hi[c] - (double)lo[c];
+                    if (!(span > 0.0)) e = -126;
+                    else {
+                        (void)std::frexp(span / 255.0, &e);  // span / 255 = m * 2^e with m in [0.5, 1): 2^e >= span / 255
+                        if (e < -126) e = -126;
+                        if (e > 127) return rrt_set_error(RRT_ERR_LIMIT, "clean tree: a node's box is too large for its byte grid");
+                    }
+                    expo[c] = (uint32_t)(e + 127);
+                    const double step = std::ldexp(1.0, e);
+                    for (uint32_t k = 0; k < n_kids; ++k) {
+                        double ql = std::floor(((double)kids[k].box[c] - (double)lo[c]) / step);
+                        double qh = std::ceil(((double)kids[k].box[4 + c] - (double)lo[c]) / step);
+                        ql = ql < 0.0 ? 0.0 : ql;
+                        qh = qh > 255.0 ? 255.0 : qh;
+                        // (the device forms plane = origin + q * step inside one fused multiply-add with the ray's terms: held here
+                        // to the exact planes in double, its rounding being a hundredth of the boxes' padding)
+                        if ((double)lo[c] + ql * step > (double)kids[k].box[c] || (double)lo[c] + qh * step < (double)kids[k].box[4 + c])
+                            return rrt_set_error(RRT_ERR_LIMIT, "clean tree: a child's box does not fit its node's byte grid");
+                        planes[2 * c] |= (uint32_t)ql << (8 * k);
+                        planes[2 * c + 1] |= (uint32_t)qh << (8 * k);
+                    }
+                }
+                float* r = &rec[(size_t)it.self * 16];
+                for (int c = 0; c < 3; ++c) r[c] = lo[c];
+                r[3] = put_u(expo[0] | (expo[1] << 8) | (expo[2] << 16));
+                for (int q = 0; q < 6; ++q) r[4 + q] = put_u(planes[q]);
                 for (uint32_t k = 0; k < n_kids; ++k) {
                     uint32_t link;
                     if (!link_of(kids[k], &link)) {
                         link = new_inner();
                         todo.push_back({kids[k], link, pending_here});
+                        r = &rec[(size_t)it.self * 16];  // (new_inner may have moved the array)
                     }
-                    float* r = &rec[(size_t)it.self * 32];
-                    for (int c = 0; c < 3; ++c) {
-                        r[8 * c + k] = kids[k].box[c];
-                        r[8 * c + 4 + k] = kids[k].box[4 + c];
-                    }
-                    r[24 + k] = put_u(link);
+                    r[10 + k] = put_u(link);
                 }
             }
             s->d.root_link = root_link;

@@ -25,9 +25,10 @@ RRT_DEV f3 xyz(v4f q) { return f3{q.x, q.y, q.z}; }
 struct DScene {
     const float4* nodes;      // 4 x float4 per node: the rrt_node (a leaf's `a` holds its first PAIR index), then the padded
                               // box its primitives occupy (lo, hi), which the TIGHT traversal tests as well: one 64-byte line.
-                              // Clean trees: inner nodes only, four-wide, 8 x float4 each: quads 0..5 hold the primitive boxes of up to
-                              // four children plane by plane (lo.x of the four, hi.x, lo.y, hi.y, lo.z, hi.z), quad 6 their links, quad 7 is
-                              // unused; a link is an inner node's index, kLinkLeaf | (pairs - 1) << 28 | first pair, or kLinkNone
+                              // Clean trees: inner nodes only, four-wide, 4 x float4 (64 bytes) each: the origin and the power-of-two steps
+                              // of the node's byte grid, the primitive boxes of up to four children as bytes on it, plane by plane (lo.x of
+                              // the four, hi.x, lo.y, hi.y, lo.z, hi.z), and their links (dwords 10..13); a link is an inner node's index,
+                              // kLinkLeaf | (pairs - 1) << 28 | first pair, or kLinkNone
     const float4* pairs;      // kPairQuads x float4 per two consecutive primitives of a leaf (see triangle_pair_eval)
     const float4* slots;      // 3 x float4 per rrt_slot
     const float4* plain;      // scenes whose textures are all Constant, without bump maps and media: 2 x float4 per slot holding all

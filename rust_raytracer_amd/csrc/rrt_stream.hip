@@ -41,7 +41,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
     r.o = r.d = thr = mk3(0.0f, 0.0f, 0.0f);
     g.s0 = g.s1 = 0;
     Walk w;
-    walk_begin(sc, w, false, r, RRT_T_MAX);
+    walk_begin<AABB_MODE>(sc, w, false, r, RRT_T_MAX);
     StreamProbe probe;
     for (;;) {
         // ---- lanes without a path draw the next samples (≙ main.rs:150-157: the queue of (pixel, sample) work items)
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
                 }
             }
             if (launch) {
-                walk_begin(sc, w, true, r, RRT_T_MAX);
+                walk_begin<AABB_MODE>(sc, w, true, r, RRT_T_MAX);
                 st = w.running ? WALK : READY;  // an empty scene answers at once
             }
             if (done) st = DEAD;
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect_stream(DScene sc, con
     Rng g;
     g.s0 = g.s1 = 0;
     Walk w;
-    walk_begin(sc, w, false, r, t_max);
+    walk_begin<AABB_MODE>(sc, w, false, r, t_max);
     for (;;) {
         const unsigned long long walking = RRT_BALLOT(st == WALK), paused = RRT_BALLOT(st == LEAF), waiting = RRT_BALLOT(st == READY || st == FRESH);
         if ((walking | paused | waiting) == 0ull) break;
@@ -211,7 +211,7 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect_stream(DScene sc, con
                 r.o = mk3(o[3 * i], o[3 * i + 1], o[3 * i + 2]);
                 r.d = mk3(d[3 * i], d[3 * i + 1], d[3 * i + 2]);
                 g = rng_seed(seed, (uint32_t)i, 0);
-                walk_begin(sc, w, true, r, t_max);
+                walk_begin<AABB_MODE>(sc, w, true, r, t_max);
                 st = w.running ? WALK : READY;  // an empty scene answers at once
             }
             continue;

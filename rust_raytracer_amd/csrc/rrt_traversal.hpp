@@ -300,6 +300,7 @@ RRT_DEV uint32_t stack_pop(const WalkStack& s, uint32_t& sp) {
     --sp;
     return sp < s.lds_entries ? s.lds[sp * s.stride] : s.beyond[sp - s.lds_entries];
 }
+template <int AABB_MODE>
 RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, float t_max) {
     w.h.slot = -1;
     w.h.t = t_max;
@@ -311,6 +312,16 @@ RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, fl
     w.held = 0u;
     w.running = active && sc.n_nodes != 0 && w.cur != kLinkNone;  // kLinkNone: a clean tree whose only leaf is empty
     w.inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
+    if (AABB_MODE == kAabbClean) {
+        // A ray that runs along an axis (a direction component of exactly zero) has an infinite inverse there, and the clean walk's
+        // fused plane test q * (step * inv) + (origin - o) * inv would turn into inf - inf: no answer, the axis would cull nothing
+        // and the ray would visit every node along its plane.  2^96 in its place keeps the test's meaning - inside the slab the
+        // interval is (-huge, +huge), beside it the interval lies beyond every distance a scene has - and stays finite.
+        const float cap = 0x1p96f;
+        if (__builtin_isinf(w.inv.x)) w.inv.x = __builtin_copysignf(cap, w.inv.x);
+        if (__builtin_isinf(w.inv.y)) w.inv.y = __builtin_copysignf(cap, w.inv.y);
+        if (__builtin_isinf(w.inv.z)) w.inv.z = __builtin_copysignf(cap, w.inv.z);
+    }
     w.down = (w.inv.x < 0.0f ? 1u : 0u) | (w.inv.y < 0.0f ? 2u : 0u) | (w.inv.z < 0.0f ? 4u : 0u);
 }
 // Visits one node (BVH::hit, aggregate.rs:343-395): an inner node that passes its test pushes one child and descends into the
@@ -319,7 +330,7 @@ template <int AABB_MODE>
 RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, const WalkStack& stack) {
     const cv4p cnodes = sc.c_nodes();
     if (AABB_MODE == kAabbClean) {
-        // One 128-byte fetch brings the boxes of up to four children: only children the ray meets are ever fetched themselves,
+        // One 64-byte fetch brings the boxes of up to four children: only children the ray meets are ever fetched themselves,
         // and leaves are not fetched at all (their pair range sits in the link).  Children are visited nearest entry first;
         // the result does not depend on the order (ties go by scene order, see coop_leaves).
         // A lane that reaches a leaf does not stop for it: it keeps the leaf's link ("held") and walks on, and stops only at the
@@ -338,19 +349,33 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, con
             w.running = false;
             return;
         }
-        const uint32_t base = 8u * w.cur;
-        // The ray's direction signs pick, per axis, which of the two plane quads is the near one: the loads fetch (near, far)
-        // instead of (lo, hi) and the interval test needs no per-axis minimum and maximum.
-        const uint32_t sx = w.down & 1u, sy = (w.down >> 1) & 1u, sz = w.down >> 2;
-        const v4f nx = cnodes[base + sx], fx = cnodes[base + (sx ^ 1u)], ny = cnodes[base + 2u + sy], fy = cnodes[base + 2u + (sy ^ 1u)],
-                  nz = cnodes[base + 4u + sz], fz = cnodes[base + 4u + (sz ^ 1u)], links = cnodes[base + 6];
+        // One 64-byte node in four loads: the grid (origin, steps), the children's planes as bytes on it, the links.
+        const uint32_t base = 4u * w.cur;
+        const v4f g0 = cnodes[base], g1 = cnodes[base + 1u], g2 = cnodes[base + 2u], g3 = cnodes[base + 3u];
+        const uint32_t expo = __float_as_uint(g0.w);
+        // t(plane) = (origin + q * step - o) * inv = q * (step * inv) + (origin - o) * inv: one fused multiply-add per plane.  Its
+        // rounding (a few ulp of the ray's distance to the node) is a hundredth of the padding the stored boxes carry.
+        const f3 a = mk3(__uint_as_float((expo & 255u) << 23) * w.inv.x, __uint_as_float(((expo >> 8) & 255u) << 23) * w.inv.y,
+                         __uint_as_float(((expo >> 16) & 255u) << 23) * w.inv.z);
+        const f3 b = mk3((g0.x - r.o.x) * w.inv.x, (g0.y - r.o.y) * w.inv.y, (g0.z - r.o.z) * w.inv.z);
+        // The ray's direction signs pick, per axis, which of the two plane dwords is the near one: no per-axis minimum and maximum.
+        const bool dx = (w.down & 1u) != 0u, dy = (w.down & 2u) != 0u, dz = (w.down & 4u) != 0u;
+        const uint32_t lox = __float_as_uint(g1.x), hix = __float_as_uint(g1.y), loy = __float_as_uint(g1.z), hiy = __float_as_uint(g1.w),
+                       loz = __float_as_uint(g2.x), hiz = __float_as_uint(g2.y);
+        const uint32_t nx = dx ? hix : lox, fx = dx ? lox : hix, ny = dy ? hiy : loy, fy = dy ? loy : hiy, nz = dz ? hiz : loz, fz = dz ? loz : hiz;
+        const uint32_t links[4] = {__float_as_uint(g2.z), __float_as_uint(g2.w), __float_as_uint(g3.x), __float_as_uint(g3.y)};
         unsigned long long key[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
-            const uint32_t link = __float_as_uint(links[k]);
-            // NaN (0 * inf: the ray lies in a plane of the box) is dropped by the maxima and minima: that plane constrains nothing
-            const float entry = __builtin_fmaxf(__builtin_fmaxf((nx[k] - r.o.x) * w.inv.x, (ny[k] - r.o.y) * w.inv.y), __builtin_fmaxf((nz[k] - r.o.z) * w.inv.z, t_min));
-            const float leave = __builtin_fminf(__builtin_fminf((fx[k] - r.o.x) * w.inv.x, (fy[k] - r.o.y) * w.inv.y), __builtin_fminf((fz[k] - r.o.z) * w.inv.z, w.h.t));
+            const uint32_t link = links[k];
+            // NaN (0 * inf, inf - inf: the ray lies in a plane of the box or runs along an axis) is dropped by the maxima and minima:
+            // that plane then constrains nothing, which can only add visits
+            const float entry = __builtin_fmaxf(__builtin_fmaxf(__builtin_fmaf((float)((nx >> (8 * k)) & 255u), a.x, b.x),
+                                                                __builtin_fmaf((float)((ny >> (8 * k)) & 255u), a.y, b.y)),
+                                                __builtin_fmaxf(__builtin_fmaf((float)((nz >> (8 * k)) & 255u), a.z, b.z), t_min));
+            const float leave = __builtin_fminf(__builtin_fminf(__builtin_fmaf((float)((fx >> (8 * k)) & 255u), a.x, b.x),
+                                                                __builtin_fmaf((float)((fy >> (8 * k)) & 255u), a.y, b.y)),
+                                                __builtin_fminf(__builtin_fmaf((float)((fz >> (8 * k)) & 255u), a.z, b.z), w.h.t));
             const bool met = entry <= leave && link != kLinkNone;
             // entry >= t_min: with a positive lower bound (a constant in the render kernels) the float's own bits order correctly
             const uint32_t order = t_min > 0.0f ? __float_as_uint(entry) : ord_bits(entry);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Throughput of rrt_intersect_batch_device (Aggregate::hit for a ray batch): python tools/perf_intersect.py [scene.json|mesh=N[,clean]] [n_rays]
+"""Throughput of rrt_intersect_batch_device (Aggregate::hit for a ray batch): python tools/perf_intersect.py [scene.json|mesh=N[,clean]] [n_rays] [lds=K]
 (mesh=N: the synthetic displaced grid of 2*N*N triangles, random rays from above it)"""
 import os
 import sys
@@ -29,6 +29,9 @@ else:
     sc = rrt.Scene.load(os.path.join(ROOT, "tests", "golden", "assets", name))
     o = torch.rand((n, 3), device="cuda", generator=g) * 500.0 + 20.0
     d = torch.randn((n, 3), device="cuda", generator=g)
+for a in sys.argv[3:]:
+    if a.startswith("lds="):
+        sc.set_lds_stack(int(a[4:]))  # stack entries per ray kept in LDS (deep trees)
 prim = torch.empty(n, dtype=torch.int32, device="cuda")
 t = torch.empty(n, dtype=torch.float32, device="cuda")
 L = rrt.lib()
