@@ -546,7 +546,7 @@ struct rrt_scene {
     std::vector<void*> owned;
     float* slab = nullptr;  // per-sample radiance staging, allocated on first render
     float* static_slab = nullptr;  // this device's copy of `scratch` (rrt_render_device_noalloc), looked up once in rrt_scene_create
-    uint32_t* d_items = nullptr;   // k_trace_pool: the pass's item counter (one word, zeroed on the stream before every launch)
+    uint32_t* d_items = nullptr;   // item counters of the persistent kernels (k_trace_pool: one word; k_trace_stream: eight, one per XCD band), zeroed on the stream before every launch
     uint32_t wave_places = 0;      // k_trace_pool: waves the device holds at kPoolWaves per SIMD (the persistent grid's size)
     bool pooling = true;           // shallow plain scenes take k_trace_pool (rrt_scene_set_pooling)
     size_t slab_bytes = 0;
@@ -1429,7 +1429,7 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
             const int mode = s->clean ? kAabbClean : (p->aabb_mode != RRT_AABB_TIGHT ? (int)RRT_AABB_REFERENCE : (int)RRT_AABB_TIGHT);
             ta.n_items = (uint32_t)items;
             const dim3 sgrid((unsigned)(items < s->wave_places ? items : s->wave_places));  // one round of the chip, see k_trace_stream
-            HIP_TRY(hipMemsetAsync(s->d_items, 0, sizeof(uint32_t), st));
+            HIP_TRY(hipMemsetAsync(s->d_items, 0, 8 * sizeof(uint32_t), st));
             HIP_TRY(launch_trace_stream(mode, (need & ~kPlain) != 0, sgrid, lds, st, s->d, ta, pass_slab, cnt, s->d_items));
         } else if (p->aabb_mode != RRT_AABB_TIGHT) RRT_PICK(RRT_AABB_REFERENCE);
         else RRT_PICK(RRT_AABB_TIGHT);

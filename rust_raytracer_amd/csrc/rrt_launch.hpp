@@ -44,8 +44,8 @@ struct TraceArgs {
 #endif
 
 // k_trace_stream<mode, features>: mode RRT_AABB_TIGHT / RRT_AABB_REFERENCE / kAabbClean, every_feature false = triangles and spheres
-// with constant textures.  The grid is persistent: ta.n_items wave items are handed out through *item_counter, which must be zero
-// when the kernel starts.  Returns hipGetLastError() of the launch.
+// with constant textures.  The grid is persistent: the wave items are handed out through item_counter[0..7] (one counter per XCD's
+// band of the frame), which must be zero when the kernel starts.  Returns hipGetLastError() of the launch.
 hipError_t launch_trace_stream(int mode, bool every_feature, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const TraceArgs& ta, float* slab,
                                unsigned long long* counters, uint32_t* item_counter);
 // k_intersect_stream<mode>

@@ -24,6 +24,14 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
     // Waves are persistent: the grid is one round of the chip, and a wave whose item (a tile of 8x8 pixels x `chunk` samples) has no
     // undrawn sample left takes the next item from an atomic counter, so lanes never stand idle while their neighbours finish the
     // item's last paths, and the launch's tail is one path long.
+    // The eight XCDs have an L2 each, and workgroups go to them round-robin by number.  The frame's tiles are therefore cut into
+    // eight bands with a counter each: a wave draws from its own XCD's band - consecutive draws are neighbouring tiles, so the
+    // waves of one XCD work side by side in the image and share the tree's nodes in that XCD's L2 - and, when its band is used
+    // up, from the next XCD's (bands cost differently: sky above, mesh below).
+    const uint32_t xcd = blockIdx.x & 7u;
+    const uint32_t band_tiles = ((ta.n_t8 + 7u) / 8u + 15u) & ~15u;  // 8x8 tiles per band: whole 32x32 tiles
+    const uint32_t n_chunks = (ta.n_samples + ta.chunk - 1u) / ta.chunk;
+    uint32_t bands_done = 0;                    // bands, its own first, that this wave has found used up
     uint32_t x0 = 0, y0 = 0, s0 = 0, pool = 0;  // the current item (wave-uniform)
     bool exhausted = false;                     // no items left in the pass
     uint32_t beyond[kMaxStackDepth];  // private memory; sized for any split of the stack the host may choose
@@ -48,16 +56,29 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
         const unsigned long long idle = RRT_BALLOT(st == DEAD);
         if (idle != 0ull && !exhausted) {
             if (next >= pool) {
-                uint32_t item = 0;
-                if (lane == 0) item = atomicAdd(item_counter, 1u);
-                item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
-                if (item >= ta.n_items) {
-                    exhausted = true;
-                } else {
-                    // Renumbered in groups of 128, the sixteen 8x8 tiles of one 32x32 tile are consecutive items: the waves that
-                    // work on neighbouring pixels at the same time share the tree's nodes in the caches.
-                    if (item < (ta.n_items & ~127u)) item = (((item >> 7) * 8u + (item & 7u)) << 4) | ((item >> 3) & 15u);
-                    const uint32_t chunk = item / ta.n_t8, j = item % ta.n_t8;
+                uint32_t chunk = 0, j = 0;
+                for (;;) {
+                    if (bands_done == 8u) {
+                        exhausted = true;
+                        break;
+                    }
+                    const uint32_t band = (xcd + bands_done) & 7u;
+                    const uint32_t first = band * band_tiles;
+                    const uint32_t count = first < ta.n_t8 ? (ta.n_t8 - first < band_tiles ? ta.n_t8 - first : band_tiles) : 0u;
+                    uint32_t c = 0;
+                    if (count != 0u) {
+                        if (lane == 0) c = atomicAdd(item_counter + band, 1u);
+                        c = (uint32_t)__builtin_amdgcn_readfirstlane((int)c);
+                    }
+                    if (count == 0u || c / count >= n_chunks) {
+                        ++bands_done;
+                        continue;
+                    }
+                    chunk = c / count;  // a band's items: all its tiles for the first samples, then for the next ...
+                    j = first + c % count;
+                    break;
+                }
+                if (!exhausted) {
                     const uint32_t tile32 = ta.tile_index + (j >> 4) * ta.tile_count;
                     x0 = (tile32 % ta.tiles_x) * 32u + ((j & 3u) << 3);
                     y0 = (tile32 / ta.tiles_x) * 32u + (((j >> 2) & 3u) << 3);
