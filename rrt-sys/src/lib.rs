@@ -4,8 +4,9 @@
 //! spelled out field for field in the header's order; the `const _: () = assert!(..)` lines state the sizes and offsets the C
 //! side asserts too (`rust_raytracer_amd/csrc/rrt_abi_layout.cpp`), so a slip on either side fails a build, not a render.
 //!
-//! Where each call replaces code of the reference's `main.rs` / `scene.rs` is noted per function; `INTEGRATION.md` shows the
-//! change in `main.rs`.
+//! Where each call replaces code of the reference's `main.rs` / `scene.rs` is noted per function: the host keeps its command line
+//! (`main.rs:38-107`) and its PNG writer (`main.rs:188-197`) and replaces queue fill, thread pool and resolve (`main.rs:115-186`) by
+//! `rrt_host_scene_load` (or the builder calls), `rrt_scene_create`, `rrt_render` / `rrt_render_multi` and `rrt_resolve_rgb8`.
 #![allow(non_camel_case_types)]
 
 use std::mem::size_of;
