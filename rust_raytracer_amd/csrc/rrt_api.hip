@@ -967,13 +967,18 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                 // the node's grid: origin = low corner of the children's common box, step 2^e per axis with 255 steps spanning it
                 float lo[3], hi[3];
                 uint32_t expo[3], planes[6] = {0u, 0u, 0u, 0u, 0u, 0u};
+                bool empty[5];  // a leaf without shapes (the description may hold one): no box, the link of an unused place
+                for (uint32_t k = 0; k < n_kids; ++k) empty[k] = kids[k].is_range && kids[k].count == 0u;
                 for (int c = 0; c < 3; ++c) {
-                    lo[c] = kids[0].box[c];
-                    hi[c] = kids[0].box[4 + c];
-                    for (uint32_t k = 1; k < n_kids; ++k) {
+                    lo[c] = std::numeric_limits<float>::infinity();
+                    hi[c] = -std::numeric_limits<float>::infinity();
+                    for (uint32_t k = 0; k < n_kids; ++k) {
+                        if (empty[k]) continue;
                         lo[c] = std::fmin(lo[c], kids[k].box[c]);
                         hi[c] = std::fmax(hi[c], kids[k].box[4 + c]);
                     }
+                    if (!(lo[c] <= hi[c])) lo[c] = hi[c] = 0.0f;  // (only empty children)
+                    if (!std::isfinite(lo[c]) || !std::isfinite(hi[c])) return rrt_set_error(RRT_ERR_INVALID, "clean tree: a primitive's box is not finite");
                     int e = 0;
                     const double span = (double)hi[c] - (double)lo[c];
                     if (!(span > 0.0)) e = -126;
@@ -985,6 +990,7 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                     expo[c] = (uint32_t)(e + 127);
                     const double step = std::ldexp(1.0, e);
                     for (uint32_t k = 0; k < n_kids; ++k) {
+                        if (empty[k]) continue;
                         double ql = std::floor(((double)kids[k].box[c] - (double)lo[c]) / step);
                         double qh = std::ceil(((double)kids[k].box[4 + c] - (double)lo[c]) / step);
                         ql = ql < 0.0 ? 0.0 : ql;
