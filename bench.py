@@ -95,12 +95,23 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_devices = torch.cuda.device_count()
+    rehearsal = world > n_devices  # more ranks than GPUs: the ranks share GPUs and talk over gloo - exercises the N > 1 code path, measures nothing
+    device_index = local_rank % n_devices
+    torch.cuda.set_device(device_index)
+    dev = torch.device("cuda", device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
+    def note(text):
+        if rehearsal:
+            print("rehearsal: rank %d %s" % (rank, text), file=sys.stderr, flush=True)
+
+    note("joined the group")
     c5 = args.config == "c5"
     if c5:
         import synth
@@ -125,6 +136,7 @@ def main():
         workload = "assets/Cornell_Box_With_Sphere.json %dx%d @ %d spp per GPU per step" % (W, H, spp)
         bytes_per_ray = float(BYTES_PER_RAY)
     upload_ms = scene.upload_seconds() * 1e3
+    note("scene uploaded")
     img = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
     host_rgb8 = torch.empty((H, W, 3), dtype=torch.uint8).pin_memory()
@@ -173,7 +185,9 @@ def main():
         tiles = kind == "tiles"
         for _ in range(warmup):
             step(kw, frame_spp, tiles)
+            note("warm-up step of %s enqueued" % kind)
         fence()
+        note("warm-up of %s done" % kind)
         counters.zero_()
         scene.kernel_times()  # forget the warm-up passes
         torch.cuda.synchronize()
@@ -184,8 +198,10 @@ def main():
             step(kw, frame_spp, tiles, e0, e1)
         fence()
         elapsed = time.perf_counter() - t0
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        c = counters.clone()
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if rehearsal else dev)
+        c = counters.cpu() if rehearsal else counters.clone()
+        if rehearsal:
+            print("rehearsal: rank %d timed %d steps of %s in %.3f s" % (rank, steps, kind, elapsed), file=sys.stderr, flush=True)
         if world > 1:
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dist.all_reduce(c, op=dist.ReduceOp.SUM)
@@ -274,6 +290,9 @@ def main():
         }
         if strong is not None:
             out["strong"] = strong
+        if rehearsal:
+            out["config"]["rehearsal"] = ("%d ranks on %d GPU(s) over gloo: the ranks share a GPU, so `value` and the strong-scaling figures only show "
+                                          "that the N > 1 path runs (render stream -> event -> collective -> resolve), not how it scales" % (world, n_devices))
         if world == 1 and args.cpu_spp > 0 and not c5:
             threads = min(len(os.sched_getaffinity(0)), 16)
             out["cpu_baseline"] = cpu_baseline(args.cpu_spp, threads)

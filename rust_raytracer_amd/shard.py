@@ -38,5 +38,12 @@ def reduce_frame(frame, dst=0):
     import torch.distributed as dist
 
     if dist.is_initialized() and dist.get_world_size() > 1:
-        dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
+        if frame.is_cuda and dist.get_backend() == "gloo":
+            # ranks that share a GPU (a rehearsal of the multi-GPU path on a box with fewer GPUs than ranks) talk over gloo, which
+            # reduces host tensors: the frame goes through the host, and every rank ends up with the sum
+            host = frame.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            frame.copy_(host)
+        else:
+            dist.reduce(frame, dst=dst, op=dist.ReduceOp.SUM)
     return frame

@@ -85,3 +85,25 @@ def test_accumulate_and_argument_checks(gpu):
         rrt.render_multi([gs[0], gs[0]], seed=1)  # one render at a time per handle
     with pytest.raises(rrt.RrtError):
         rrt.render_multi(gs, shard=5)
+
+
+def test_bench_with_two_ranks_sharing_the_gpu(gpu):
+    """bench.py's N > 1 path on real hardware: two ranks under torch.distributed.run on the box's single GPU (they share it and talk
+    over gloo - a rehearsal, it measures nothing): render on its own stream, event, collective, resolve, and the strong-scaling
+    figures (sample ranges and tiles) must come out, with the ray count of ONE frame for the strong cases."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29517",
+           os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--spp", "32"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=170, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1
+    rec = json.loads(line[0])
+    assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and "rehearsal" in rec["config"]
+    assert rec["value"] > 0 and rec["roofline"]["kernel"] == "k_trace_pool"
+    assert set(rec["strong"]) == {"samples", "tiles"} and all(v["value"] > 0 for v in rec["strong"].values())
