@@ -135,7 +135,12 @@ def main():
         scene = rrt.Scene(host)  # upload happens here, outside the timed region
         workload = "assets/Cornell_Box_With_Sphere.json %dx%d @ %d spp per GPU per step" % (W, H, spp)
         bytes_per_ray = float(BYTES_PER_RAY)
-    upload_ms = scene.upload_seconds() * 1e3
+    upload_ms = scene.upload_seconds() * 1e3  # the process's first handle: includes loading the library's code object onto the device
+    upload_warm_ms = upload_ms
+    if not c5:  # (the mesh's upload is 2 GB of copies either way)
+        second = rrt.Scene(host)  # what a scene costs once the process is warm
+        upload_warm_ms = second.upload_seconds() * 1e3
+        second.close()
     note("scene uploaded")
     img = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
     rgb8 = torch.zeros((H, W, 3), dtype=torch.uint8, device=dev)
@@ -285,7 +290,9 @@ def main():
                        "samples_per_second": paths_total / elapsed, "rays_per_path": rays_total / max(paths_total, 1),
                        "time_to_image_ms": upload_ms + step_ms + d2h_ms,
                        "time_to_image_parts_ms": {"scene_upload": upload_ms, "render_reduce_resolve": step_ms, "rgb8_to_host": d2h_ms,
-                                                  "host_load_and_build_not_included": build_s * 1e3}},
+                                                  "host_load_and_build_not_included": build_s * 1e3,
+                                                  "scene_upload_in_a_warm_process": upload_warm_ms},
+                       "time_to_image_warm_ms": upload_warm_ms + step_ms + d2h_ms},
             "roofline": roofline,
         }
         if strong is not None:
