@@ -13,13 +13,13 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define REP8(x) x x x x x x x x
 #define REP32(x) REP8(x) REP8(x) REP8(x) REP8(x)
 
-enum { MUL_VV, FMA_VVV, MUL_VS, MAX_VV, MIN3, CMP, CNDMASK, PK_MUL, PK_FMA, PK_FMA_S, RCP, SQRT, MOV, ADD_U32, KINDS };
+enum { MUL_VV, FMA_VVV, MUL_VS, MAX_VV, MIN3, CMP, CNDMASK, CNDMASK_OTHER_DST, CNDMASK_SGPR, CNDMASK_CONST, CNDMASK_E64_VCC, CNDMASK_VALU_VCC, CMP_THEN_CNDMASK, CMP_3CND, CMP_3CND_E64, CND_MUL, SALU_VCC_CND_3MUL, PK_MUL, PK_FMA, PK_FMA_S, RCP, SQRT, MOV, ADD_U32, KINDS };
 static const char* kNames[KINDS] = {"v_mul_f32 v,v,v", "v_fma_f32 v,v,v,v", "v_mul_f32 v,s,v", "v_max_f32 v,v,v", "v_min3_f32 v,v,v,v", "v_cmp_lt_f32 vcc,v,v",
-                                    "v_cndmask_b32 v,v,v,vcc", "v_pk_mul_f32 v,v,v", "v_pk_fma_f32 v,v,v,v", "v_pk_fma_f32 v,s,v,v", "v_rcp_f32", "v_sqrt_f32",
+                                    "v_cndmask_b32 v,v,v,vcc", "v_cndmask_b32 w,v,v,vcc", "v_cndmask_b32 v,v,v,s[a:b]", "v_cndmask_b32 v,0,1.0,vcc", "v_cndmask_b32_e64 v,v,v,vcc", "v_cndmask e32, vcc from v_cmp", "v_cmp + v_cndmask e32 (pair)", "v_cmp + 3 v_cndmask e32", "v_cmp + 3 v_cndmask e64", "v_cndmask e32, v_mul (pair)", "s_mov vcc, cndmask e32, 2 mul", "v_pk_mul_f32 v,v,v", "v_pk_fma_f32 v,v,v,v", "v_pk_fma_f32 v,s,v,v", "v_rcp_f32", "v_sqrt_f32",
                                     "v_mov_b32 v,v", "v_add_u32 v,v,v"};
 
 // 4 independent accumulators, 32 x 4 = 128 instructions per loop turn
-#define BODY(text) REP32(asm volatile(text : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(x), "s"(s0), "v"(px), "s"(ss) : "vcc");)
+#define BODY(text) REP32(asm volatile(text : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3) : "v"(x), "s"(s0), "v"(px), "s"(ss) : "vcc", "s20", "s21");)
 
 template <int KIND>
 __global__ __launch_bounds__(64) void k(unsigned long long* ticks, const float* in, int iters, float s0) {
@@ -28,7 +28,8 @@ __global__ __launch_bounds__(64) void k(unsigned long long* ticks, const float* 
     v2f ss = {s0, s0};
     unsigned long long t0, t1, r0, r1;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n s_memrealtime %0\n s_memtime %1\n s_waitcnt lgkmcnt(0)" : "=s"(r0), "=s"(t0)::"memory");
-    asm volatile("s_mov_b32 vcc_lo, 0x55555555\n s_mov_b32 vcc_hi, 0x55555555" ::: "vcc");  // a defined mask for the select
+    asm volatile("s_mov_b32 vcc_lo, 0x55555555\n s_mov_b32 vcc_hi, 0x55555555\n s_mov_b32 s20, 0x33333333\n s_mov_b32 s21, 0x33333333" ::: "vcc", "s20", "s21");  // defined masks for the selects
+    if (KIND == CNDMASK_VALU_VCC) asm volatile("v_cmp_lt_f32 vcc, %0, %1" ::"v"(a0), "v"(x) : "vcc");  // the mask written by the vector ALU
     for (int i = 0; i < iters; ++i) {
         if (KIND == MUL_VV) { BODY("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8") }
         if (KIND == FMA_VVV) { BODY("v_fma_f32 %0, %0, %8, %8\n v_fma_f32 %1, %1, %8, %8\n v_fma_f32 %2, %2, %8, %8\n v_fma_f32 %3, %3, %8, %8") }
@@ -37,6 +38,16 @@ __global__ __launch_bounds__(64) void k(unsigned long long* ticks, const float* 
         if (KIND == MIN3) { BODY("v_min3_f32 %0, %0, %8, %8\n v_min3_f32 %1, %1, %8, %8\n v_min3_f32 %2, %2, %8, %8\n v_min3_f32 %3, %3, %8, %8") }
         if (KIND == CMP) { BODY("v_cmp_lt_f32 vcc, %0, %8\n v_cmp_lt_f32 vcc, %1, %8\n v_cmp_lt_f32 vcc, %2, %8\n v_cmp_lt_f32 vcc, %3, %8") }
         if (KIND == CNDMASK) { BODY("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc") }
+        if (KIND == CNDMASK_OTHER_DST) { BODY("v_cndmask_b32 %0, %1, %8, vcc\n v_cndmask_b32 %1, %2, %8, vcc\n v_cndmask_b32 %2, %3, %8, vcc\n v_cndmask_b32 %3, %0, %8, vcc") }
+        if (KIND == CNDMASK_SGPR) { BODY("v_cndmask_b32_e64 %0, %0, %8, s[20:21]\n v_cndmask_b32_e64 %1, %1, %8, s[20:21]\n v_cndmask_b32_e64 %2, %2, %8, s[20:21]\n v_cndmask_b32_e64 %3, %3, %8, s[20:21]") }
+        if (KIND == CNDMASK_CONST) { BODY("v_cndmask_b32_e64 %0, 0, 1.0, vcc\n v_cndmask_b32_e64 %1, 0, 1.0, vcc\n v_cndmask_b32_e64 %2, 0, 1.0, vcc\n v_cndmask_b32_e64 %3, 0, 1.0, vcc") }
+        if (KIND == CNDMASK_E64_VCC) { BODY("v_cndmask_b32_e64 %0, %0, %8, vcc\n v_cndmask_b32_e64 %1, %1, %8, vcc\n v_cndmask_b32_e64 %2, %2, %8, vcc\n v_cndmask_b32_e64 %3, %3, %8, vcc") }
+        if (KIND == CNDMASK_VALU_VCC) { BODY("v_cndmask_b32 %0, %0, %8, vcc\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc") }
+        if (KIND == CMP_THEN_CNDMASK) { BODY("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cmp_lt_f32 vcc, %2, %8\n v_cndmask_b32 %3, %3, %8, vcc") }
+        if (KIND == CMP_3CND) { BODY("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32 %1, %1, %8, vcc\n v_cndmask_b32 %2, %2, %8, vcc\n v_cndmask_b32 %3, %3, %8, vcc") }
+        if (KIND == CMP_3CND_E64) { BODY("v_cmp_lt_f32 vcc, %0, %8\n v_cndmask_b32_e64 %1, %1, %8, vcc\n v_cndmask_b32_e64 %2, %2, %8, vcc\n v_cndmask_b32_e64 %3, %3, %8, vcc") }
+        if (KIND == CND_MUL) { BODY("v_cndmask_b32 %0, %0, %8, vcc\n v_mul_f32 %1, %1, %8\n v_cndmask_b32 %2, %2, %8, vcc\n v_mul_f32 %3, %3, %8") }
+        if (KIND == SALU_VCC_CND_3MUL) { BODY("s_mov_b64 vcc, exec\n v_cndmask_b32 %0, %0, %8, vcc\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8") }
         if (KIND == PK_MUL) { BODY("v_pk_mul_f32 %4, %4, %10\n v_pk_mul_f32 %5, %5, %10\n v_pk_mul_f32 %6, %6, %10\n v_pk_mul_f32 %7, %7, %10") }
         if (KIND == PK_FMA) { BODY("v_pk_fma_f32 %4, %4, %10, %10\n v_pk_fma_f32 %5, %5, %10, %10\n v_pk_fma_f32 %6, %6, %10, %10\n v_pk_fma_f32 %7, %7, %10, %10") }
         if (KIND == PK_FMA_S) { BODY("v_pk_fma_f32 %4, %11, %4, %10\n v_pk_fma_f32 %5, %11, %5, %10\n v_pk_fma_f32 %6, %11, %6, %10\n v_pk_fma_f32 %7, %11, %7, %10") }
@@ -104,6 +115,16 @@ int main() {
     run<MIN3>(d_ticks, d_in, cus);
     run<CMP>(d_ticks, d_in, cus);
     run<CNDMASK>(d_ticks, d_in, cus);
+    run<CNDMASK_OTHER_DST>(d_ticks, d_in, cus);
+    run<CNDMASK_SGPR>(d_ticks, d_in, cus);
+    run<CNDMASK_CONST>(d_ticks, d_in, cus);
+    run<CNDMASK_E64_VCC>(d_ticks, d_in, cus);
+    run<CNDMASK_VALU_VCC>(d_ticks, d_in, cus);
+    run<CMP_THEN_CNDMASK>(d_ticks, d_in, cus);
+    run<CMP_3CND>(d_ticks, d_in, cus);
+    run<CMP_3CND_E64>(d_ticks, d_in, cus);
+    run<CND_MUL>(d_ticks, d_in, cus);
+    run<SALU_VCC_CND_3MUL>(d_ticks, d_in, cus);
     run<PK_MUL>(d_ticks, d_in, cus);
     run<PK_FMA>(d_ticks, d_in, cus);
     run<PK_FMA_S>(d_ticks, d_in, cus);
