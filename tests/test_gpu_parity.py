@@ -498,3 +498,35 @@ def test_pooled_schedule_with_a_depth_limit_and_many_lights(gpu):
         img, st = g2.render(samples=6, seed=5, background=rrt.BG_SKY)
         same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
         assert same.all() and st["rays"] == int(st_ref[0]), pooled
+
+
+@pytest.mark.parametrize("tree", ["BVH", "BVH_CLEAN"])
+def test_deep_tree_frames_do_not_depend_on_how_the_work_is_handed_out(gpu, tree):
+    """The deep-tree kernel's waves are persistent and take (tile, samples) items from eight counters, one per band of the frame,
+    stealing from the next band when theirs is used up; on large frames the tiles of a band are numbered column by column.  None of
+    it may show in the image: a ragged frame against the oracle, the same frame from interleaved tile subsets and from many small
+    passes, and a frame large enough for the column order against its two tile subsets."""
+    d = synth.terrain_desc(100, seed=4, width=200, height=136, samples=3)
+    g = rrt.Scene(synth.host_scene(d, tree))
+    o = orc.OracleScene(d if tree == "BVH" else dict(d, aggregate=0))  # a clean tree answers like the reference's List
+    ref, st_ref = o.render(200, 136, 3, seed=6, threads=min(16, len(__import__("os").sched_getaffinity(0))))
+    full, st = g.render(seed=6)
+    same = (bits(full) == bits(ref)) | (np.isnan(full) & np.isnan(ref))
+    assert same.all(), "%d of %d values differ" % ((~same).sum(), same.size)
+    assert st["rays"] == int(st_ref[0]) and st["paths"] == 200 * 136 * 3
+    tiled = np.zeros_like(full)
+    for k in range(3):
+        g.render(seed=6, tile_count=3, tile_index=k, out=tiled)
+    assert np.array_equal(bits(tiled), bits(full))
+    g.set_staging_limit(200 * 136 * 12)  # one sample per pass
+    again, st2 = g.render(seed=6)
+    assert np.array_equal(bits(again), bits(full)) and st2["rays"] == st["rays"]
+    g.set_staging_limit(16 << 30)
+    W, H = 2048, 1600  # 64 x 50 tiles of 32 x 32: bands of 7 rows = 448 tiles, numbered by columns
+    big, st_big = g.render(width=W, height=H, samples=1, seed=2)
+    halves = np.zeros_like(big)
+    rays = 0
+    for k in range(2):
+        _, s = g.render(width=W, height=H, samples=1, seed=2, tile_count=2, tile_index=k, out=halves)
+        rays += s["rays"]
+    assert ((bits(halves) == bits(big)) | (np.isnan(halves) & np.isnan(big))).all() and rays == st_big["rays"] and st_big["paths"] == W * H
