@@ -12,10 +12,11 @@ namespace {
 // Same work and same results as k_trace, other schedule.  On a large mesh the rays of a wave need very
 // different numbers of node visits (a mean of 300 against 2 000 for the slowest lane of a wave on a 10 M-triangle mesh), and a
 // loop that runs query - shade - query in step leaves most lanes idle most of the time.  Here every lane is a small state
-// machine - FRESH (has a pool sample, no ray yet), WALK (visiting nodes), LEAF (paused at a leaf), READY (query finished) -
-// and the wave's loop does, each turn: one node for the WALK lanes; a cooperative leaf phase when enough lanes are paused;
-// a shading phase (shade, store, draw the next sample, make the camera ray) when enough lanes are READY or FRESH.  A lane
-// that finishes its query early is shaded and sent walking again while its neighbours are still in their queries.
+// machine - DEAD (no path: takes the next undrawn sample), FRESH (has a sample, no ray yet), WALK (visiting nodes), LEAF (stands
+// at a leaf), READY (query finished) - and the wave's loop does, each turn: hand samples to the DEAD lanes; a few node steps for
+// the WALK lanes; a cooperative leaf phase when enough lanes stand at (or hold) a leaf; a shading phase (shade, store the sample
+// of a path that ended, make the camera ray of a fresh one) when enough lanes are READY or FRESH.  A lane that finishes its query
+// early is shaded and sent walking again while its neighbours are still in their queries.
 template <int AABB_MODE, uint32_t FEAT>
 __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stream(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters,
                                                                                    uint32_t* __restrict__ item_counter) {
