@@ -85,8 +85,10 @@ typedef struct rrt_sphere {
     uint32_t pad[6];
 } rrt_sphere;
 
-/* ConstantMedium (volume.rs:44-48).  boundary_kind is RRT_KIND_SPHERE (index into spheres[]) or
- * RRT_KIND_TRIANGLE (index into boundary_tris[] / boundary_tri_shade[]). */
+/* ConstantMedium (volume.rs:44-48).  boundary_kind is RRT_KIND_SPHERE (index into spheres[]), RRT_KIND_TRIANGLE (index into
+ * boundary_tris[] / boundary_tri_shade[]) or RRT_KIND_MEDIUM (index into media[], of an EARLIER record: scene.rs:588 lets the
+ * boundary be any single shape, a ConstantMedium included).  A chain of media may be RRT_MAX_MEDIUM_NESTING records long. */
+#define RRT_MAX_MEDIUM_NESTING 3
 typedef struct rrt_medium {
     uint32_t boundary_kind;
     uint32_t boundary_index;
@@ -246,6 +248,9 @@ int rrt_host_add_mesh(rrt_host_scene*, const float translate[3], const float rot
                       const int32_t* tidx, int cull, int32_t material);
 int rrt_host_add_medium_sphere(rrt_host_scene*, const float translate[3], const float rotate[3], const float scale[3], float radius,
                                int32_t boundary_material, float density, int32_t phase_material); /* scene.rs:573-602 */
+/* scene.rs:573-602 when the boundary's own "type" is "ConstantMedium": the shape added last, which must be a medium, leaves the
+ * scene's list and becomes the boundary of a new medium, which takes its place. */
+int rrt_host_wrap_last_medium(rrt_host_scene*, float density, int32_t phase_material);
 int rrt_host_set_camera(rrt_host_scene*, const float position[3], const float look_at[3], const float up[3], float fov, float aspect,
                         float aperture, float focus_distance); /* camera.rs:66-88 */
 int rrt_host_set_logistics(rrt_host_scene*, uint32_t resolution_x, uint32_t resolution_y, uint32_t samples, int use_importance_sampling);

@@ -908,25 +908,30 @@ struct HitCtx {  // what a stochastic primitive needs to make its keyed draw
     uint32_t depth;
     Stats* stats;
 };
-static bool shape_hit(const Scene& sc, const Shape& s, const Ray& r, float t_min, float t_max, const HitCtx& cx, float* t_out);
+static bool shape_hit(const Scene& sc, const Shape& s, const Ray& r, float t_min, float t_max, const HitCtx& cx, float* t_out, uint32_t tag);
+// The reference draws from the thread's generator every time a medium is asked (volume.rs:95), so a medium that serves as the
+// boundary of another one draws twice per question put to the outer one (volume.rs:66, 71-73).  Here every draw is keyed: a
+// medium in the scene's list by its index there, the boundary medium of a medium with key `tag` by a hash of `tag` and of which
+// of the two questions it is.
+static inline uint32_t medium_child_tag(uint32_t tag, uint32_t question) { return mix32(tag + 0x632be5abu * (question + 1u)); }
 // volume.rs:65-102
-static bool medium_hit(const Scene& sc, const Shape& s, const Ray& r, float t_min, float t_max, const HitCtx& cx, float* t_out) {
+static bool medium_hit(const Scene& sc, const Shape& s, const Ray& r, float t_min, float t_max, const HitCtx& cx, float* t_out, uint32_t tag) {
     const Shape& b = sc.boundaries[s.boundary];
     float t_hit1, t_hit2;
-    if (!shape_hit(sc, b, r, -kTMax, kTMax, cx, &t_hit1)) return false;
-    if (!shape_hit(sc, b, r, t_hit1 + kEps, kTMax, cx, &t_hit2)) return false;
+    if (!shape_hit(sc, b, r, -kTMax, kTMax, cx, &t_hit1, medium_child_tag(tag, 0))) return false;
+    if (!shape_hit(sc, b, r, t_hit1 + kEps, kTMax, cx, &t_hit2, medium_child_tag(tag, 1))) return false;
     if (t_hit1 < t_min) t_hit1 = t_min;
     if (t_hit2 > t_max) t_hit2 = t_max;
     if (t_hit1 >= t_hit2) return false;
     if (t_hit1 < 0.0f) t_hit1 = 0.0f;
     float distance_inside_boundary = (t_hit2 - t_hit1) * length(r.dir);
-    float xi = rng_keyed_f32(*cx.rng, cx.depth, (uint32_t)s.id);
+    float xi = rng_keyed_f32(*cx.rng, cx.depth, tag);
     float hit_dist = (-1.0f / s.density) * dm_log(xi);
     if (hit_dist > distance_inside_boundary) return false;
     *t_out = t_hit1 + (hit_dist / length(r.dir));
     return true;
 }
-static bool shape_hit(const Scene& sc, const Shape& s, const Ray& r, float t_min, float t_max, const HitCtx& cx, float* t_out) {
+static bool shape_hit(const Scene& sc, const Shape& s, const Ray& r, float t_min, float t_max, const HitCtx& cx, float* t_out, uint32_t tag) {
     switch (s.type) {
         case SHAPE_SPHERE:
             if (cx.stats) cx.stats->sphere_tests++;
@@ -935,7 +940,7 @@ static bool shape_hit(const Scene& sc, const Shape& s, const Ray& r, float t_min
             if (cx.stats) cx.stats->tri_tests++;
             return triangle_hit(sc, s, r, t_min, t_max, t_out);
         default:
-            return medium_hit(sc, s, r, t_min, t_max, cx, t_out);
+            return medium_hit(sc, s, r, t_min, t_max, cx, t_out, tag);
     }
 }
 static HitProps shape_hit_properties(const Scene& sc, const Shape& s, const Ray& r, float t) {
@@ -977,7 +982,7 @@ static bool list_hit(const Scene& sc, const std::vector<int>& list, const Ray& r
     int hit_shape = -1;
     for (int idx : list) {
         float t;
-        if (shape_hit(sc, sc.shapes[idx], r, t_min, modified_t_max, cx, &t)) {
+        if (shape_hit(sc, sc.shapes[idx], r, t_min, modified_t_max, cx, &t, (uint32_t)idx)) {
             modified_t_max = t;
             hit_shape = idx;
         }
@@ -1507,6 +1512,24 @@ int orc_add_medium_sphere(void* s, const float* translate, const float* rotate, 
 int orc_add_medium_last_boundary(void* s, float density, int phase_material) {
     Scene* sc = (Scene*)s;
     if (sc->boundaries.empty()) { sc->error = "no boundary"; return -1; }
+    Shape m{};
+    m.type = SHAPE_MEDIUM;
+    m.boundary = (int)sc->boundaries.size() - 1;
+    m.density = density;
+    m.material = phase_material;
+    m.id = (int)sc->shapes.size();
+    sc->shapes.push_back(m);
+    return m.id;
+}
+// scene.rs:573-602 when the boundary's own "type" is "ConstantMedium": the medium added last leaves the scene's list and
+// becomes the boundary of a new one, which takes its place
+int orc_wrap_last_medium(void* s, float density, int phase_material) {
+    Scene* sc = (Scene*)s;
+    if (sc->shapes.empty() || sc->shapes.back().type != SHAPE_MEDIUM) { sc->error = "no medium to wrap"; return -1; }
+    Shape inner = sc->shapes.back();
+    sc->shapes.pop_back();
+    inner.id = -1;
+    sc->boundaries.push_back(inner);
     Shape m{};
     m.type = SHAPE_MEDIUM;
     m.boundary = (int)sc->boundaries.size() - 1;

@@ -256,6 +256,8 @@ extern "C" {
     /// scene.rs:573-602
     pub fn rrt_host_add_medium_sphere(s: *mut rrt_host_scene, translate: *const f32, rotate: *const f32, scale: *const f32, radius: f32,
                                       boundary_material: i32, density: f32, phase_material: i32) -> c_int;
+    /// scene.rs:573-602 with a ConstantMedium for a boundary: the medium added last becomes the boundary of a new one
+    pub fn rrt_host_wrap_last_medium(s: *mut rrt_host_scene, density: f32, phase_material: i32) -> c_int;
     /// camera.rs:66-88
     pub fn rrt_host_set_camera(s: *mut rrt_host_scene, position: *const f32, look_at: *const f32, up: *const f32, fov: f32, aspect: f32,
                                aperture: f32, focus_distance: f32) -> c_int;

@@ -124,6 +124,7 @@ def lib():
     L.rrt_host_add_sphere.argtypes = [vp, _f3, _f3, _f3, C.c_float, C.c_int32]
     L.rrt_host_add_mesh.argtypes = [vp, _f3, _f3, _f3, C.c_uint32, vp, C.c_uint32, vp, C.c_uint32, vp, vp, C.c_int, C.c_int32]
     L.rrt_host_add_medium_sphere.argtypes = [vp, _f3, _f3, _f3, C.c_float, C.c_int32, C.c_float, C.c_int32]
+    L.rrt_host_wrap_last_medium.argtypes = [vp, C.c_float, C.c_int32]
     L.rrt_host_set_camera.argtypes = [vp, _f3, _f3, _f3, C.c_float, C.c_float, C.c_float, C.c_float]
     L.rrt_host_set_logistics.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
     L.rrt_host_finalize.argtypes = [vp, C.c_int]
@@ -223,6 +224,11 @@ class HostScene:
         _check(lib().rrt_host_add_medium_sphere(self._h, _vec(translate), _vec(rotate), _vec(scale), radius, boundary_material, density,
                                                 phase_material))
 
+    def wrap_last_medium(self, density, phase_material):
+        """The medium added last becomes the boundary of a new one, which takes its place in the scene (scene.rs:573-602 with a
+        ConstantMedium for a boundary)."""
+        _check(lib().rrt_host_wrap_last_medium(self._h, density, phase_material))
+
     def set_camera(self, position, look_at, up, fov, aspect_ratio, aperture, focus_distance):
         _check(lib().rrt_host_set_camera(self._h, _vec(position), _vec(look_at), _vec(up), fov, aspect_ratio, aperture, focus_distance))
 
@@ -260,6 +266,13 @@ class HostScene:
                                           ("v2", "f4", 3), ("e1", "f4", 3), ("e2", "f4", 3), ("nrm", "f4", 3), ("pad", "u4", 2)])
         if d.n_lights:
             C.memmove(out.ctypes.data, d.lights, out.nbytes)
+        return out
+
+    def media(self):
+        d = self.desc
+        out = np.zeros(d.n_media, dtype=[("boundary_kind", "u4"), ("boundary_index", "u4"), ("density", "f4"), ("material", "u4")])
+        if d.n_media:
+            C.memmove(out.ctypes.data, d.media, out.nbytes)
         return out
 
     def textures(self):

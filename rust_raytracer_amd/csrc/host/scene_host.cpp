@@ -206,6 +206,22 @@ std::string SceneBuild::add_medium_last_boundary_triangle(float density, int32_t
     return "";
 }
 
+// scene.rs:588-600 with a ConstantMedium for a boundary: the medium added last stops being a shape of the scene and becomes the
+// boundary of a new one (same box: volume.rs:112-114 passes the boundary's on)
+std::string SceneBuild::wrap_last_medium(float density, int32_t phase) {
+    if (phase < 0 || (size_t)phase >= materials.size()) return "Missing Phase Function for ConstantMedium.";
+    if (shapes.empty() || shapes.back().kind != RRT_KIND_MEDIUM) return "Only single shapes are allowed for constant mediums at the moment.";
+    const uint32_t inner = shapes.back().index;
+    uint32_t chain = 2;
+    for (uint32_t m = inner; media[m].boundary_kind == RRT_KIND_MEDIUM; m = media[m].boundary_index) ++chain;
+    if (chain > RRT_MAX_MEDIUM_NESTING)
+        return "A ConstantMedium inside a ConstantMedium inside ... : this build follows " + std::to_string(RRT_MAX_MEDIUM_NESTING) + " of them at most.";
+    media.push_back(rrt_medium{RRT_KIND_MEDIUM, inner, density, (uint32_t)phase});
+    shapes.back().index = (uint32_t)media.size() - 1;
+    shapes.back().material = (uint32_t)phase;
+    return "";
+}
+
 void SceneBuild::set_camera(Vec3 pos, Vec3 look_at, Vec3 up, float fov, float aspect, float aperture, float focus) {
     // camera.rs:22-51
     float theta = to_radians(fov);
@@ -362,7 +378,9 @@ std::string SceneBuild::finalize(int aggregate) {
             const HostShape* s = &s0;
             rrt_light l{};
             if (s->kind == RRT_KIND_MEDIUM) {  // pdf / random_dir_towards delegate to the boundary (volume.rs:116-122)
-                const rrt_medium& m = media[s->index];
+                uint32_t mi = s->index;
+                while (media[mi].boundary_kind == RRT_KIND_MEDIUM) mi = media[mi].boundary_index;
+                const rrt_medium& m = media[mi];
                 if (m.boundary_kind == RRT_KIND_SPHERE) {
                     l.kind = RRT_KIND_SPHERE;
                     l.index = m.boundary_index;
@@ -479,6 +497,13 @@ int rrt_host_add_medium_sphere(rrt_host_scene* s, const float* tr, const float* 
     RRT_NEED(s && tr && rot && scl);
     return rrt_guard("rrt_host_add_medium_sphere", [&]() -> int {
         std::string e = s->b.add_medium_sphere(v3p(tr), v3p(rot), v3p(scl), radius, bmat, density, phase);
+        return e.empty() ? RRT_OK : fail_scene(e);
+    });
+}
+int rrt_host_wrap_last_medium(rrt_host_scene* s, float density, int32_t phase) {
+    RRT_NEED(s);
+    return rrt_guard("rrt_host_wrap_last_medium", [&]() -> int {
+        std::string e = s->b.wrap_last_medium(density, phase);
         return e.empty() ? RRT_OK : fail_scene(e);
     });
 }

@@ -54,6 +54,7 @@ struct SceneBuild {
                          const int32_t* vidx, const int32_t* tidx, bool cull, int32_t material, bool as_boundary);
     std::string add_medium_sphere(Vec3 tr, Vec3 rot, Vec3 scl, float radius, int32_t boundary_material, float density, int32_t phase);
     std::string add_medium_last_boundary_triangle(float density, int32_t phase);
+    std::string wrap_last_medium(float density, int32_t phase);
     void set_camera(Vec3 pos, Vec3 look_at, Vec3 up, float fov, float aspect, float aperture, float focus);
     std::string finalize(int aggregate);  // RRT_AGGREGATE_*
 };

@@ -438,13 +438,14 @@ struct Loader {
             return count;
         }
         if (ty == "ConstantMedium") {  // scene.rs:573-602
-            if (as_boundary) bail("A ConstantMedium whose boundary is itself a ConstantMedium is not supported by this build.");
             const Json& boundary = required(j, "boundary");
             float dens = as_f32(required(j, "density"), "density");
             const std::string& pname = as_str(required(j, "phase_func"), "phase_func");
             auto it = materials.find(pname);
             if (it == materials.end()) bail("Missing Phase Function " + pname + " for ConstantMedium.");
             if (shape(boundary, true, dens, it->second) != 1) bail("Only single shapes are allowed for constant mediums at the moment.");
+            // this medium is itself a boundary: the one just added becomes the boundary of the one that asked
+            if (as_boundary) check(sb->wrap_last_medium(density, phase));
             return 1;
         }
         bail("Unknown Shape 'type' " + ty + " given.");

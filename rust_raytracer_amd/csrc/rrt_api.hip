@@ -438,7 +438,7 @@ __global__ __launch_bounds__(kBlock) void k_intersect(DScene sc, const float* __
     }
     Rng g = rng_seed(seed, (uint32_t)i, 0);
     unsigned char* area = (unsigned char*)(lds_stack + kBlock * stack_depth) + (threadIdx.x >> 6) * kSiftBytesPerWave;
-    const Hit h = closest_hit_sift<AABB_MODE, F_ALL>(sc, active, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock, area);
+    const Hit h = closest_hit_sift<AABB_MODE, F_EVERY>(sc, active, r, t_min, t_max, g, 0, lds_stack + threadIdx.x, kBlock, area);
     if (!active) return;
     prim[i] = h.slot >= 0 ? (int)__float_as_uint(sc.slots[3 * h.slot].w) : -1;
     t_hit[i] = h.t;
@@ -490,7 +490,7 @@ __global__ void k_probe(DScene sc, uint32_t which, uint32_t arg, uint32_t W, uin
         hit.u = hit.v = hit.det = 0.0f;
         if (RRT_INFO_KIND(__float_as_uint(sc.slots[3 * slot + 1].w)) == RRT_KIND_TRIANGLE)
             triangle_uvdet(xyz(sc.slots[3 * slot]), xyz(sc.slots[3 * slot + 1]), xyz(sc.slots[3 * slot + 2]), r, &hit.u, &hit.v, &hit.det);
-        HitProps h = slot_props<F_ALL>(sc, hit, r, &mat);
+        HitProps h = slot_props<F_EVERY>(sc, hit, r, &mat);
         q[0] = h.p.x; q[1] = h.p.y; q[2] = h.p.z; q[3] = h.n.x; q[4] = h.n.y; q[5] = h.n.z; q[6] = h.u; q[7] = h.v;
         q[8] = h.pu.x; q[9] = h.pu.y; q[10] = h.pu.z; q[11] = h.pv.x; q[12] = h.pv.y; q[13] = h.pv.z;
     } else if (which == 2) {
@@ -603,7 +603,12 @@ static int validate_desc(const rrt_scene_desc* d, uint32_t* tree_depth) {
         if (m.material >= d->n_materials) BAD("medium phase function out of range");
         if (m.boundary_kind == RRT_KIND_SPHERE) { if (m.boundary_index >= d->n_spheres) BAD("medium boundary sphere out of range"); }
         else if (m.boundary_kind == RRT_KIND_TRIANGLE) { if (m.boundary_index >= d->n_boundary_tris) BAD("medium boundary triangle out of range"); }
-        else BAD("unknown medium boundary kind");
+        else if (m.boundary_kind == RRT_KIND_MEDIUM) {  // an earlier record, so chains end; kernels follow RRT_MAX_MEDIUM_NESTING records
+            if (m.boundary_index >= i) BAD("medium boundary medium must be an earlier record");
+            uint32_t chain = 2;
+            for (uint32_t k = m.boundary_index; d->media[k].boundary_kind == RRT_KIND_MEDIUM; k = d->media[k].boundary_index) ++chain;
+            if (chain > RRT_MAX_MEDIUM_NESTING) BAD("media nested deeper than RRT_MAX_MEDIUM_NESTING");
+        } else BAD("unknown medium boundary kind");
     }
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const rrt_material& m = d->materials[i];
@@ -710,7 +715,9 @@ static void pair_box(const rrt_scene_desc* d, uint32_t first, uint32_t count, fl
         if (kind == RRT_KIND_TRIANGLE) grow_triangle(b, sl);
         else if (kind == RRT_KIND_SPHERE) grow_sphere(b, d->spheres[sl.aux]);
         else {
-            const rrt_medium& m = d->media[sl.aux];
+            uint32_t mi = sl.aux;  // every distance a medium reports lies between its boundary's two (volume.rs:79-101)
+            while (d->media[mi].boundary_kind == RRT_KIND_MEDIUM) mi = d->media[mi].boundary_index;
+            const rrt_medium& m = d->media[mi];
             if (m.boundary_kind == RRT_KIND_SPHERE) grow_sphere(b, d->spheres[m.boundary_index]);
             else grow_triangle(b, d->boundary_tris[m.boundary_index]);
         }
@@ -1091,6 +1098,9 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         if (kind == RRT_KIND_SPHERE) s->features |= F_SPHERE;
         if (kind == RRT_KIND_MEDIUM) s->features |= F_MEDIUM | F_SPHERE;
     }
+    for (uint32_t i = 0; i < desc->n_media; ++i) {
+        if (desc->media[i].boundary_kind == RRT_KIND_MEDIUM) s->features |= F_NESTED;
+    }
     for (uint32_t i = 0; i < desc->n_lights; ++i)
         if (desc->lights[i].kind == RRT_KIND_SPHERE) s->features |= F_SPHERE;
     for (uint32_t i = 0; i < desc->n_textures; ++i)
@@ -1360,7 +1370,8 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
     // 243.5 and 49.4 / 48.6 / 49.6 / 52.5 ms.)
     ta.walk_steps = 6;
     hipStream_t st = (hipStream_t)stream;
-    // compiled variants: plain (triangles + spheres, constant textures), textured (+ textures, bump maps), full (+ media)
+    // compiled variants: plain (triangles + spheres, constant textures), textured (+ textures, bump maps), full (+ media), and
+    // full with media that bound media (rare, and the code for it costs the scenes with ordinary media 5 % when it rides along)
     constexpr uint32_t kPlain = F_SPHERE, kTextured = F_SPHERE | F_TEX | F_BUMP;
     const uint32_t need = s->features;
     unsigned long long* cnt = (unsigned long long*)d_counters;
@@ -1400,7 +1411,8 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
         // shallow trees: the pooled schedule (k_trace_pool) - a persistent grid that hands the items out itself
         if (exhaustive) {
             // the yardstick mode on a shallow tree: one kernel variant (every feature, one path per lane); speed is not its point
-            hipLaunchKernelGGL((k_trace<kAabbExhaustive, F_ALL>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt);
+            if (need & F_NESTED) hipLaunchKernelGGL((k_trace<kAabbExhaustive, F_EVERY>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt);
+            else hipLaunchKernelGGL((k_trace<kAabbExhaustive, F_ALL>), grid, dim3(kTraceBlock), lds, st, s->d, ta, pass_slab, cnt);
         } else if (pooled) {
             ta.n_items = (uint32_t)items;
             const dim3 pgrid((unsigned)(items < s->wave_places ? items : s->wave_places));
@@ -1414,6 +1426,7 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
             if (s->harvest) RRT_LAUNCH_POOL(MODE, kPlain, true);             \
             else RRT_LAUNCH_POOL(MODE, kPlain, false);                       \
         } else if ((need & ~kTextured) == 0) RRT_LAUNCH_POOL(MODE, kTextured, false); \
+        else if (need & F_NESTED) RRT_LAUNCH_POOL(MODE, F_EVERY, false);     \
         else RRT_LAUNCH_POOL(MODE, F_ALL, false);                            \
     } while (0)
             if (p->aabb_mode == RRT_AABB_REFERENCE) RRT_PICK_POOL(RRT_AABB_REFERENCE);
@@ -1429,6 +1442,7 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
             else RRT_LAUNCH(MODE, kPlain);                                           \
         }                                                                            \
         else if ((need & ~kTextured) == 0) RRT_LAUNCH(MODE, kTextured);              \
+        else if (need & F_NESTED) RRT_LAUNCH(MODE, F_EVERY);                         \
         else RRT_LAUNCH(MODE, F_ALL);                                                \
     } while (0)
         if (s->deep) {  // (clean trees are deep by definition)
@@ -1436,7 +1450,7 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
             ta.n_items = (uint32_t)items;
             const dim3 sgrid((unsigned)(items < s->wave_places ? items : s->wave_places));  // one round of the chip, see k_trace_stream
             HIP_TRY(hipMemsetAsync(s->d_items, 0, 8 * sizeof(uint32_t), st));
-            HIP_TRY(launch_trace_stream(mode, (need & ~kPlain) != 0, sgrid, lds, st, s->d, ta, pass_slab, cnt, s->d_items));
+            HIP_TRY(launch_trace_stream(mode, need, sgrid, lds, st, s->d, ta, pass_slab, cnt, s->d_items));
         } else if (p->aabb_mode != RRT_AABB_TIGHT) RRT_PICK(RRT_AABB_REFERENCE);
         else RRT_PICK(RRT_AABB_TIGHT);
         }

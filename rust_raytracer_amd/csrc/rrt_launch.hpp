@@ -43,10 +43,10 @@ struct TraceArgs {
 #define RRT_TRACE_MIN_WAVES 4  // waves per SIMD the register allocator must leave room for (128 VGPRs)
 #endif
 
-// k_trace_stream<mode, features>: mode RRT_AABB_TIGHT / RRT_AABB_REFERENCE / kAabbClean, every_feature false = triangles and spheres
-// with constant textures.  The grid is persistent: the wave items are handed out through item_counter[0..7] (one counter per XCD's
+// k_trace_stream<mode, features>: mode RRT_AABB_TIGHT / RRT_AABB_REFERENCE / kAabbClean; `features` = the F_* bits the scene needs (three variants:
+// triangles and spheres with constant textures, everything but nested media, everything).  The grid is persistent: the wave items are handed out through item_counter[0..7] (one counter per XCD's
 // band of the frame), which must be zero when the kernel starts.  Returns hipGetLastError() of the launch.
-hipError_t launch_trace_stream(int mode, bool every_feature, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const TraceArgs& ta, float* slab,
+hipError_t launch_trace_stream(int mode, uint32_t features, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const TraceArgs& ta, float* slab,
                                unsigned long long* counters, uint32_t* item_counter);
 // k_intersect_stream<mode>
 hipError_t launch_intersect_stream(int mode, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const float* o, const float* d, size_t n, float t_min,

@@ -114,27 +114,72 @@ RRT_DEV bool sphere_hit_m(P w2l, float radius, const Ray& r, float t_min, float 
 RRT_DEV bool sphere_hit(csphere_p s, const Ray& r, float t_min, float t_max, float* t_out) {
     return sphere_hit_m((cf1p)s->w2l, s->radius, r, t_min, t_max, t_out);
 }
-// The boundary shape of a medium: a sphere or a single triangle.
+// The boundary shape of a medium that is a sphere or a single triangle.
 RRT_DEV bool boundary_hit(const DScene& sc, cmedium_p m, const Ray& r, float t_min, float t_max, float* t_out) {
     if (m->boundary_kind == RRT_KIND_SPHERE) return sphere_hit(sc.c_spheres() + m->boundary_index, r, t_min, t_max, t_out);
     const cv4p bt = sc.c_btris() + 3 * m->boundary_index;
     const v4f q0 = bt[0], q1 = bt[1], q2 = bt[2];
     return triangle_hit(xyz(q0), xyz(q1), xyz(q2), (__float_as_uint(q1.w) & RRT_INFO_CULL) != 0, r, t_min, t_max, t_out);
 }
-// ConstantMedium::hit (volume.rs:65-102); xi is the uniform draw of line 95
-RRT_DEV bool medium_hit(const DScene& sc, cmedium_p m, const Ray& r, float t_min, float t_max, float xi, float* t_out) {
-    float t1, t2;
-    if (!boundary_hit(sc, m, r, -RRT_T_MAX, RRT_T_MAX, &t1)) return false;
-    if (!boundary_hit(sc, m, r, t1 + RRT_EPS, RRT_T_MAX, &t2)) return false;
+// ConstantMedium::hit (volume.rs:65-102) from line 79 on: `t1`, `t2` are what the boundary answered, xi is the uniform draw of line 95
+RRT_DEV bool medium_sample(float t1, float t2, float dir_len, float density, float t_min, float t_max, float xi, float* t_out) {
     if (t1 < t_min) t1 = t_min;
     if (t2 > t_max) t2 = t_max;
     if (t1 >= t2) return false;
     if (t1 < 0.0f) t1 = 0.0f;
-    float distance_inside = (t2 - t1) * len3(r.d);
-    float hit_dist = (-1.0f / m->density) * det_log(xi);
+    float distance_inside = (t2 - t1) * dir_len;
+    float hit_dist = (-1.0f / density) * det_log(xi);
     if (hit_dist > distance_inside) return false;
-    *t_out = t1 + (hit_dist / len3(r.d));
+    *t_out = t1 + (hit_dist / dir_len);
     return true;
+}
+// ConstantMedium::hit (volume.rs:65-102) with a sphere or a triangle for a boundary
+RRT_DEV bool medium_hit(const DScene& sc, cmedium_p m, const Ray& r, float t_min, float t_max, float xi, float* t_out) {
+    float t1, t2;
+    if (!boundary_hit(sc, m, r, -RRT_T_MAX, RRT_T_MAX, &t1)) return false;
+    if (!boundary_hit(sc, m, r, t1 + RRT_EPS, RRT_T_MAX, &t2)) return false;
+    return medium_sample(t1, t2, len3(r.d), m->density, t_min, t_max, xi, t_out);
+}
+// A medium whose boundary is a medium (scene.rs:588 accepts any single shape).  The outer medium puts its two questions
+// (volume.rs:66, 71-73) to the inner one, which answers each with a draw of its own; the innermost medium's questions go to a
+// sphere or a triangle and do not depend on who asks, so that pair of distances is found once.  `density[0]` is the innermost
+// medium's.  Every draw is keyed: the medium in the scene's list by `tag` = its index there, a boundary medium by a hash of its
+// owner's key and of which of the two questions it is.
+RRT_DEV uint32_t medium_child_tag(uint32_t tag, uint32_t question) { return mix32(tag + 0x632be5abu * (question + 1u)); }
+template <int LEVEL>
+RRT_DEV bool medium_level(const float* density, float s1, float s2, float dir_len, float t_min, float t_max, const Rng& key, uint32_t depth,
+                          uint32_t tag, float* t_out) {
+    float t1 = s1, t2 = s2;
+    if constexpr (LEVEL > 0) {
+        if (!medium_level<LEVEL - 1>(density, s1, s2, dir_len, -RRT_T_MAX, RRT_T_MAX, key, depth, medium_child_tag(tag, 0), &t1)) return false;
+        if (!medium_level<LEVEL - 1>(density, s1, s2, dir_len, t1 + RRT_EPS, RRT_T_MAX, key, depth, medium_child_tag(tag, 1), &t2)) return false;
+    }
+    return medium_sample(t1, t2, dir_len, density[LEVEL], t_min, t_max, rng_keyed(key, depth, tag), t_out);
+}
+RRT_DEV bool medium_hit_nested(const DScene& sc, cmedium_p m, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t tag,
+                               float* t_out) {
+    float density[RRT_MAX_MEDIUM_NESTING];  // outermost first while the chain is followed
+    int levels = 0;
+    const cmedium_p media = sc.c_media();
+    for (;;) {
+        density[levels++] = m->density;
+        if (m->boundary_kind != RRT_KIND_MEDIUM || levels == RRT_MAX_MEDIUM_NESTING) break;  // (the host refuses longer chains)
+        m = media + m->boundary_index;
+    }
+    float s1, s2;
+    if (!boundary_hit(sc, m, r, -RRT_T_MAX, RRT_T_MAX, &s1)) return false;
+    if (!boundary_hit(sc, m, r, s1 + RRT_EPS, RRT_T_MAX, &s2)) return false;
+    const float dir_len = len3(r.d);
+    static_assert(RRT_MAX_MEDIUM_NESTING == 3, "one case per chain length below");
+    if (levels == 2) {
+        const float d[2] = {density[1], density[0]};
+        return medium_level<1>(d, s1, s2, dir_len, t_min, t_max, key, depth, tag, t_out);
+    }
+    if (levels == 3) {
+        const float d[3] = {density[2], density[1], density[0]};
+        return medium_level<2>(d, s1, s2, dir_len, t_min, t_max, key, depth, tag, t_out);
+    }
+    return medium_level<0>(density, s1, s2, dir_len, t_min, t_max, key, depth, tag, t_out);
 }
 
 // ---- bounding boxes (aggregate.rs:471-503) ---------------------------------------------------------------------

@@ -75,7 +75,9 @@ RRT_DEV HitProps slot_props(const DScene& sc, const Hit& hit, const Ray& r, uint
     if (!(FEAT & (F_SPHERE | F_MEDIUM)) || kind == RRT_KIND_TRIANGLE) return triangle_props(sc.c_tri_shade() + 4 * slot, r, hit.t, hit.u, hit.v, hit.det, want_uv);
     const uint32_t aux = __float_as_uint(cslots[3 * slot + 2].w);
     if ((FEAT & F_SPHERE) && kind == RRT_KIND_SPHERE) return sphere_props(sc.c_spheres() + aux, r, hit.t, want_uv);
-    const cmedium_p m = sc.c_media() + aux;  // volume.rs:104-106
+    cmedium_p m = sc.c_media() + aux;  // volume.rs:104-106: the boundary's properties, whatever the boundary is
+    if (FEAT & F_NESTED)
+        for (int i = 1; i < RRT_MAX_MEDIUM_NESTING && m->boundary_kind == RRT_KIND_MEDIUM; ++i) m = sc.c_media() + m->boundary_index;
     if (m->boundary_kind == RRT_KIND_SPHERE) return sphere_props(sc.c_spheres() + m->boundary_index, r, hit.t, want_uv);
     const uint32_t bi = m->boundary_index;
     const cv4p bt = sc.c_btris() + 3 * bi;

@@ -262,10 +262,10 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect_stream(DScene sc, con
         if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
             if (AABB_MODE == kAabbClean) {
                 const bool has = w.held != 0u;
-                coop_leaves<F_ALL, true>(sc, r, t_min, g, 0, has, link_first_pair(w.held), link_pairs(w.held), w.h, coop);
+                coop_leaves<F_EVERY, true>(sc, r, t_min, g, 0, has, link_first_pair(w.held), link_pairs(w.held), w.h, coop);
                 if (has) st = walk_after_held(w, stack) ? (w.running ? WALK : LEAF) : READY;
             } else {
-                coop_leaves<F_ALL, false>(sc, r, t_min, g, 0, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
+                coop_leaves<F_EVERY, false>(sc, r, t_min, g, 0, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
                 if (st == LEAF) {
                     walk_resume(w, stack);
                     st = w.running ? WALK : READY;
@@ -279,12 +279,13 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect_stream(DScene sc, con
 
 namespace rrt {
 
-hipError_t launch_trace_stream(int mode, bool every_feature, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const TraceArgs& ta, float* slab,
+hipError_t launch_trace_stream(int mode, uint32_t features, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const TraceArgs& ta, float* slab,
                                unsigned long long* counters, uint32_t* item_counter) {
     constexpr uint32_t kPlain = F_SPHERE;
 #define RRT_GO(MODE)                                                                                                                       \
     do {                                                                                                                                   \
-        if (every_feature) hipLaunchKernelGGL((k_trace_stream<MODE, F_ALL>), grid, dim3(kTraceBlock), lds, st, sc, ta, slab, counters, item_counter);   \
+        if (features & F_NESTED) hipLaunchKernelGGL((k_trace_stream<MODE, F_EVERY>), grid, dim3(kTraceBlock), lds, st, sc, ta, slab, counters, item_counter); \
+        else if (features & ~kPlain) hipLaunchKernelGGL((k_trace_stream<MODE, F_ALL>), grid, dim3(kTraceBlock), lds, st, sc, ta, slab, counters, item_counter); \
         else hipLaunchKernelGGL((k_trace_stream<MODE, kPlain>), grid, dim3(kTraceBlock), lds, st, sc, ta, slab, counters, item_counter);                \
     } while (0)
     if (mode == kAabbClean) RRT_GO(kAabbClean);

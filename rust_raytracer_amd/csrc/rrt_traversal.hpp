@@ -15,7 +15,9 @@ enum : uint32_t {
     F_MEDIUM = 2u,  // ConstantMedium primitives and the Isotropic phase function
     F_TEX = 4u,     // textures other than Constant (needs uv / world point in texture lookups)
     F_BUMP = 8u,    // bump maps (needs pu, pv)
-    F_ALL = 15u
+    F_ALL = 15u,    // all of the above
+    F_NESTED = 16u, // media whose boundary is a medium
+    F_EVERY = 31u
 };
 
 
@@ -51,8 +53,11 @@ RRT_DEV void test_slot(const DScene& sc, uint32_t s, const Ray& r, float t_min, 
         }
     } else if (FEAT & F_MEDIUM) {
         float t;
-        float xi = rng_keyed(key, depth, __float_as_uint(q0.w));
-        if (medium_hit(sc, sc.c_media() + __float_as_uint(q2.w), r, t_min, h.t, xi, &t)) {
+        const cmedium_p m = sc.c_media() + __float_as_uint(q2.w);
+        const uint32_t tag = __float_as_uint(q0.w);  // the shape's index in scene order
+        const bool found = (FEAT & F_NESTED) && m->boundary_kind == RRT_KIND_MEDIUM ? medium_hit_nested(sc, m, r, t_min, h.t, key, depth, tag, &t)
+                                                                                     : medium_hit(sc, m, r, t_min, h.t, rng_keyed(key, depth, tag), &t);
+        if (found) {
             h.t = t;
             h.slot = (int)s;
         }

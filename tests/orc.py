@@ -50,6 +50,7 @@ def lib():
     L.orc_add_mesh.argtypes = [vp, f32p, f32p, f32p, C.c_uint32, f64p, C.c_uint32, f64p, C.c_uint32, i32p, i32p, C.c_int, C.c_int, C.c_int]
     L.orc_add_medium_sphere.argtypes = [vp, f32p, f32p, f32p, C.c_float, C.c_int, C.c_float, C.c_int]
     L.orc_add_medium_last_boundary.argtypes = [vp, C.c_float, C.c_int]
+    L.orc_wrap_last_medium.argtypes = [vp, C.c_float, C.c_int]
     L.orc_set_camera.argtypes = [vp, f32p, f32p, f32p, C.c_float, C.c_float, C.c_float, C.c_float]
     L.orc_set_logistics.argtypes = [vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_int]
     L.orc_finalize.argtypes = [vp, C.c_int]
@@ -166,8 +167,9 @@ class OracleScene:
             elif b["type"] == "mesh":
                 self._add_mesh(b, True)
                 self._check(L.orc_add_medium_last_boundary(self.h, s["density"], s["phase"]))
-            else:
-                raise sceneio.SceneError("nested ConstantMedium boundaries are not supported")
+            else:  # a medium inside a medium: the inner one first, then it becomes the boundary of this one
+                self._add_shape(b)
+                self._check(L.orc_wrap_last_medium(self.h, s["density"], s["phase"]))
 
     def close(self):
         if self.h:

@@ -54,9 +54,11 @@ def soup_desc(n=3000, seed=7, width=40, height=32, samples=2):
     return d
 
 
-def spheres_desc(n=40, seed=3, width=48, height=40, samples=4, media=0):
+def spheres_desc(n=40, seed=3, width=48, height=40, samples=4, media=0, nested=False):
     """Rotated, anisotropically scaled spheres (whose reference bounding box, centre +- radius, ignores the scale and so does
-    not contain them), a few with negative radius, over a two-triangle floor; Lambert, Metal, Dielectric and one light."""
+    not contain them), a few with negative radius, over a two-triangle floor; Lambert, Metal, Dielectric and one light.
+    media: that many constant-density media bounded by spheres; nested: every medium but each third one becomes the boundary
+    of a second medium, and each third of those of a third."""
     rng = np.random.default_rng(seed)
     shapes = []
     for i in range(n):
@@ -71,7 +73,14 @@ def spheres_desc(n=40, seed=3, width=48, height=40, samples=4, media=0):
         tr[1] = float(rng.uniform(0.5, 2.0))
         sc = [float(v) for v in rng.uniform(0.8, 2.0, 3)]
         boundary = {"type": "sphere", "radius": float(rng.uniform(0.4, 0.9)), "material": 0, "transform": (tr, [0.0, 0.0, 0.0], sc)}
-        shapes.insert(int(rng.integers(0, len(shapes))), {"type": "medium", "boundary": boundary, "density": float(rng.uniform(0.5, 3.0)), "phase": 4})
+        medium = {"type": "medium", "boundary": boundary, "density": float(rng.uniform(0.5, 3.0)), "phase": 4}
+        where = int(rng.integers(0, len(shapes)))
+        if nested and i % 3 != 2:
+            # an outer medium is stopped inside the short stretch between its boundary's two answers: densities grow outwards
+            medium = {"type": "medium", "boundary": medium, "density": 6.0 + 2.0 * (i % 4), "phase": 4}
+            if i % 3 == 0:
+                medium = {"type": "medium", "boundary": medium, "density": 30.0 + 10.0 * (i % 4), "phase": 4}
+        shapes.insert(where, medium)
     floor_v = np.array([[-8, 0, -8], [8, 0, -8], [8, 0, 8], [-8, 0, 8]], dtype=np.float64)
     floor_t = np.array([[0, 2, 1], [0, 3, 2]], dtype=np.int32)
     shapes.append({"type": "mesh", "object": {"vertices": floor_v, "tex": np.zeros((0, 2)), "vidx": floor_t, "tidx": np.full_like(floor_t, -1)},
@@ -165,10 +174,15 @@ def host_scene(desc, aggregate=None):
         hs.add_material(m["type"], m["albedo"], m["bump"], m["param"])
     for s in desc["shapes"]:
         if s["type"] == "medium":
-            b = s["boundary"]
+            chain = [s]
+            while chain[-1]["boundary"]["type"] == "medium":
+                chain.append(chain[-1]["boundary"])
+            b = chain[-1]["boundary"]
             assert b["type"] == "sphere"
             btr, bro, bsc = b["transform"]
-            hs.add_medium_sphere(b["radius"], b["material"], s["density"], s["phase"], btr, bro, bsc)
+            hs.add_medium_sphere(b["radius"], b["material"], chain[-1]["density"], chain[-1]["phase"], btr, bro, bsc)
+            for outer in reversed(chain[:-1]):
+                hs.wrap_last_medium(outer["density"], outer["phase"])
             continue
         tr, ro, sc = s["transform"]
         if s["type"] == "sphere":

@@ -219,6 +219,56 @@ def test_scaled_spheres_outside_their_reference_boxes_bit_exact(gpu, media):
         assert st["rays"] == int(st_ref[0])
 
 
+@pytest.mark.parametrize("n,aggregate", [(40, 1), (4, 1), (6, 0)])
+def test_media_bounded_by_media_bit_exact(gpu, n, aggregate):
+    """A ConstantMedium may bound a ConstantMedium (scene.rs:588): the outer one asks the inner one twice (volume.rs:66-73) and
+    each answer is a draw of its own.  Two and three media deep, in a deep tree (the streaming kernel), a shallow one and a List
+    (the pooled and the one-path-per-lane kernels), in every box mode, and in the clean tree against the oracle's List."""
+    d = synth.spheres_desc(n=n, media=6, nested=True)
+    d["aggregate"] = aggregate
+    nested = [i for i, s in enumerate(d["shapes"]) if s["type"] == "medium" and s["boundary"]["type"] == "medium"]
+    deepest = [i for i in nested if d["shapes"][i]["boundary"]["boundary"]["type"] == "medium"]
+    assert len(nested) == 4 and len(deepest) == 2
+    o = orc.OracleScene(d)
+    hs = synth.host_scene(d)
+    assert len(hs.media()) == 6 + 4 + 2
+    g = rrt.Scene(hs)
+    ro, rd = raygen.ray_batch(o, 48, 40, n_random=8000, seed=4)
+    rng = np.random.default_rng(9)
+    for i in nested:  # and rays aimed at the nested media from all around, some starting inside
+        b = d["shapes"][i]
+        while b["type"] == "medium":
+            b = b["boundary"]
+        centre = np.float32(b["transform"][0])
+        start = (centre + rng.normal(0.0, 1.0, (700, 3)) * rng.choice([0.3, 2.0, 5.0], (700, 1))).astype(np.float32)
+        aim = (centre + rng.uniform(-0.4, 0.4, (700, 3))).astype(np.float32)
+        ro, rd = np.concatenate([ro, start]), np.concatenate([rd, aim - start])
+    for t_min in (0.001, -1.0):
+        p_ref, t_ref = o.intersect(ro, rd, t_min=t_min)
+        assert np.isin(p_ref, nested).sum() > 400 and np.isin(p_ref, deepest).sum() > 25, "too few rays stop inside the nested media to tell"
+        for mode in (rrt.AABB_TIGHT, rrt.AABB_REFERENCE, rrt.AABB_EXHAUSTIVE):
+            p, t = g.hit(ro, rd, t_min=t_min, aabb_mode=mode)
+            assert np.array_equal(p, p_ref), "primitive ids differ in mode %d: %d rays" % (mode, (p != p_ref).sum())
+            assert np.array_equal(bits(t), bits(t_ref))
+    ref, st_ref = o.render(48, 40, 6, seed=2, bg=rrt.BG_SKY)
+    for pooled in (True, False):
+        g.set_pooling(pooled)
+        for mode in (rrt.AABB_TIGHT, rrt.AABB_REFERENCE, rrt.AABB_EXHAUSTIVE):
+            img, st = g.render(samples=6, seed=2, background=rrt.BG_SKY, aabb_mode=mode)
+            same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+            assert same.all(), "%d of %d values differ (pooled %s, mode %d)" % ((~same).sum(), same.size, pooled, mode)
+            assert st["rays"] == int(st_ref[0])
+    o_list = orc.OracleScene(dict(d, aggregate=0))
+    g_clean = rrt.Scene(synth.host_scene(d, "BVH_CLEAN"))
+    p_ref, t_ref = o_list.intersect(ro, rd)
+    p, t = g_clean.hit(ro, rd)
+    assert np.array_equal(p, p_ref) and np.array_equal(bits(t), bits(t_ref))
+    ref, st_ref = o_list.render(48, 40, 6, seed=2, bg=rrt.BG_SKY)
+    img, st = g_clean.render(samples=6, seed=2, background=rrt.BG_SKY)
+    same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+    assert same.all() and st["rays"] == int(st_ref[0])
+
+
 @pytest.mark.parametrize("aggregate,n", [(0, 40), (1, 40), (0, 7)])
 def test_one_big_leaf_with_ties_bit_exact(gpu, aggregate, n):
     """Stacked quads whose boxes most rays cross (the candidate list of a wave overflows and is flushed in parts), shapes

@@ -11,6 +11,11 @@ import orc
 import sceneio
 import rust_raytracer_amd as rrt
 
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SCENES = ["Cornell_Box.json", "Cornell_Box_With_Sphere.json", "Materials.json", "Example_Spec.json", "Globe.json"]
 
@@ -172,6 +177,64 @@ def test_mesh_rules(tmp_path):
     with pytest.raises(rrt.RrtError) as e:
         load_variant(tmp_path, m)
     assert "Triangle mesh has length 3 but attempted to make a Triangle with indices 0, 1, 8." in e.value.message
+
+
+def test_a_medium_may_be_the_boundary_of_a_medium(tmp_path):
+    """scene.rs:588 hands the boundary to deserialize_shape, so a ConstantMedium may bound a ConstantMedium.  The flattened
+    scene holds one record per medium, the outer one pointing at the inner; box, light sampling and the scene's shape count are
+    those of the innermost boundary (volume.rs:104-122)."""
+    (tmp_path / "t.obj").write_text("o T\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    (tmp_path / "q.obj").write_text("o Q\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\n")
+    ball = {"type": "Sphere", "radius": 0.5, "material": "M", "transform": {"translate": [2, 0, 0]}}
+    tri = {"type": "Mesh", "file_path": "t.obj", "enable_backface_culling": False, "material": "M"}
+
+    def medium(boundary, density, phase="I"):
+        return {"type": "ConstantMedium", "boundary": boundary, "density": density, "phase_func": phase}
+
+    def m(s):
+        s["Materials"]["I"] = {"type": "Isotropic", "albedo": "T"}
+        s["Materials"]["G"] = {"type": "Dielectric", "refractive_index": 1.5}
+        s["Shapes"] = [medium(medium(ball, 1.0), 2.0), {"type": "Sphere", "radius": 1, "material": "M"},
+                       medium(medium(medium(tri, 3.0), 4.0), 5.0, "G")]
+
+    hs = load_variant(tmp_path, m)
+    assert hs.desc.n_slots == 3 and hs.desc.n_spheres == 2 and hs.desc.n_boundary_tris == 1
+    media = hs.media()
+    assert [(int(r["boundary_kind"]), int(r["boundary_index"]), float(r["density"])) for r in media] == \
+        [(1, 0, 1.0), (2, 0, 2.0), (0, 0, 3.0), (2, 2, 4.0), (2, 3, 5.0)]
+    slots = hs.slots()
+    by_prim = {int(r["prim"]): r for r in slots}
+    assert by_prim[0]["info"] >> 30 == 2 and by_prim[0]["aux"] == 1 and by_prim[2]["info"] >> 30 == 2 and by_prim[2]["aux"] == 4
+    lights = hs.lights()  # the glass-phased medium is "important" (scene.rs:131-140); its pdf is the triangle's
+    assert len(lights) == 1 and lights[0]["kind"] == 0 and np.array_equal(lights[0]["v1"], [1, 0, 0])
+    o = orc.OracleScene.from_file(str(tmp_path / "v.json"))
+    assert o.num_shapes() == 3 and list(o.important()) == [2]
+    assert np.array_equal(slots["prim"].astype(np.int32), o.bvh()[2])
+    assert np.array_equal(bits(hs.nodes()["bmin"]), bits(o.bvh()[0][:, :3])) and np.array_equal(bits(hs.nodes()["bmax"]), bits(o.bvh()[0][:, 3:]))
+
+    def too_deep(s):
+        m(s)
+        s["Shapes"] = [medium(medium(medium(medium(ball, 1.0), 2.0), 3.0), 4.0)]
+
+    with pytest.raises(rrt.RrtError) as e:
+        load_variant(tmp_path, too_deep)
+    assert e.value.code == 2 and "this build follows 3 of them at most" in e.value.message
+
+    def two_shapes(s):
+        m(s)
+        s["Shapes"] = [medium(medium({"type": "Mesh", "file_path": "q.obj", "enable_backface_culling": False, "material": "M"}, 1.0), 2.0)]
+
+    with pytest.raises(rrt.RrtError) as e:
+        load_variant(tmp_path, two_shapes)
+    assert "Only single shapes are allowed for constant mediums at the moment." in e.value.message
+
+    def no_phase(s):
+        m(s)
+        s["Shapes"] = [medium(medium(ball, 1.0, "Nope"), 2.0)]
+
+    with pytest.raises(rrt.RrtError) as e:
+        load_variant(tmp_path, no_phase)
+    assert "Missing Phase Function Nope for ConstantMedium." in e.value.message
 
 
 def test_builder_api_and_list_aggregate():

@@ -206,6 +206,68 @@ def test_scene_level_facts():
     assert p[0] >= 0 and t[0] == pytest.approx(1355.0, rel=1e-6)
 
 
+def _medium_scene(densities):
+    """A unit sphere at the origin bounding a medium of densities[0], which bounds a medium of densities[1], and so on."""
+    shape = {"type": "sphere", "radius": 1.0, "material": 0, "transform": ([0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])}
+    for rho in densities:
+        shape = {"type": "medium", "boundary": shape, "density": rho, "phase": 1}
+    return orc.OracleScene({
+        "textures": [{"type": 0, "color": (0.5, 0.5, 0.5)}],
+        "materials": [{"type": 0, "albedo": 0, "bump": -1, "param": 0.0}, {"type": 4, "albedo": 0, "bump": -1, "param": 0.0}],
+        "shapes": [shape], "aggregate": 0,
+        "camera": {"position": [0, 0, 5], "look_at": [0, 0, 0], "up": [0, 1, 0], "fov": 40, "aspect_ratio": 1.0, "aperture": 0.0, "focus_distance": 1.0},
+        "logistics": {"resolution_x": 8, "resolution_y": 8, "samples": 1, "use_importance_sampling": False}})
+
+
+def _reference_medium(rng, n, t_in, t_out, densities, t_min, t_max):
+    """ConstantMedium::hit (volume.rs:65-102) for n independent questions, in float64 with numpy's generator; densities[0] is
+    the innermost medium's, whose boundary answers t_in, then t_out.  Returns distances, NaN where the answer is None."""
+    def ask(level, lo, hi):
+        if level < 0:  # the sphere: first root inside (lo, hi), else the second
+            first = np.where((t_in > lo) & (t_in < hi), t_in, np.where((t_out > lo) & (t_out < hi), t_out, np.nan))
+            return np.broadcast_to(first, (n,)).astype(np.float64)
+        big = np.finfo(np.float32).max
+        t1 = ask(level - 1, np.full(n, -big), np.full(n, big))
+        t2 = ask(level - 1, t1 + np.finfo(np.float32).eps, np.full(n, big))
+        t1 = np.maximum(t1, lo)
+        t2 = np.minimum(t2, hi)
+        ok = t1 < t2  # False where either is NaN
+        t1 = np.maximum(t1, 0.0)
+        dist = -np.log(rng.random(n)) / densities[level]  # unit direction
+        return np.where(ok & (dist <= t2 - t1), t1 + dist, np.nan)
+    return ask(len(densities) - 1, np.full(n, t_min), np.full(n, t_max))
+
+
+@pytest.mark.parametrize("densities", [(0.8,), (3.0, 0.6), (1.5, 2.0, 0.9)])
+def test_constant_medium_distances_follow_the_reference_algorithm(densities):
+    """The reference draws from a generator that cannot be seeded (volume.rs:95), so a medium's answers are pinned as a
+    distribution: how often a ray through the sphere's centre is stopped, and the mean and spread of where, against the
+    algorithm written out independently (float64, numpy's generator) - for a plain medium also against the closed form
+    1 - exp(-density * chord).  A medium that bounds a medium is asked twice per question put to the outer one and must draw
+    afresh each time."""
+    sc = _medium_scene(densities)
+    n = 200000
+    o = np.tile(np.float32([0, 0, 3]), (n, 1))
+    d = np.tile(np.float32([0, 0, -1]), (n, 1))
+    prim, t = sc.intersect(o, d, seed=11)
+    hit = prim >= 0
+    assert np.all(prim[hit] == 0) and np.all((t[hit] >= 2.0) & (t[hit] <= 4.0))
+    ref = _reference_medium(np.random.default_rng(5), 1000000, 2.0, 4.0, densities, 0.001, float(np.finfo(np.float32).max))
+    p_ref = np.mean(~np.isnan(ref))
+    if len(densities) == 1:
+        assert abs(p_ref - (1.0 - math.exp(-densities[0] * 2.0))) < 2e-3
+    sigma = math.sqrt(p_ref * (1 - p_ref) * (1 / n + 1e-6))
+    assert abs(hit.mean() - p_ref) < 4.5 * sigma, (hit.mean(), p_ref)
+    spread = np.nanstd(ref)
+    assert abs(t[hit].mean() - np.nanmean(ref)) < 4.5 * spread * math.sqrt(1 / hit.sum() + 1e-6)
+    assert abs(t[hit].std() - spread) < 0.01
+    # every ray drew for itself: a repeated batch repeats, another seed does not
+    prim2, t2 = sc.intersect(o, d, seed=11)
+    assert np.array_equal(prim, prim2) and np.array_equal(t, t2)
+    prim3, _ = sc.intersect(o, d, seed=12)
+    assert (prim3 != prim).mean() > 0.05
+
+
 def test_resolve_saturates():
     img = np.zeros((1, 4, 3), dtype=np.float32)
     img[0, 0] = [15.0, 0.25, 1.0]
