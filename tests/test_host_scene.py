@@ -332,6 +332,56 @@ def test_image_decoders_survive_hostile_files_under_asan(tmp_path):
     assert "fuzz ok" in r.stdout
 
 
+def test_scene_loader_survives_hostile_files_under_asan(tmp_path):
+    """A scene file and its .obj file cut short at every length, with every number replaced by hostile spellings (huge, negative,
+    not a number, another JSON type), with seeded random damage and with hundreds of thousands of opening brackets: the loader,
+    built here from the library's host sources with AddressSanitizer and UBSan, must refuse or load every file without touching
+    memory out of bounds, and what it loads must hold only indices in range (tests/fuzz_scene_loader.cpp)."""
+    import shutil
+    import subprocess
+
+    from PIL import Image
+
+    if not shutil.which("g++"):
+        pytest.skip("no host compiler")
+    rng = np.random.default_rng(0)
+    Image.fromarray(rng.integers(0, 256, (8, 12, 3), dtype=np.uint8)).save(tmp_path / "a.png")
+    (tmp_path / "m.obj").write_text("o A\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nvt 0 0\nvt 1 0\nvt 1 1\nvt 0 1\nf 1/1 2/2 3/3 4/4\n"
+                                    "o B\nv 0 0 1\nv 1 0 1\nv 0 1 1\nf 5 6 7\nf -3 -2 -1\n")
+    (tmp_path / "t.obj").write_text("o T\nv 0 0 0\nv 1 0 0\nv 0 1 0\nf 1 2 3\n")
+    ball = {"type": "Sphere", "radius": 0.5, "material": "M", "transform": {"translate": [2, 0, 0], "rotate": [10, 20, 30], "scale": [1, 2, 1]}}
+
+    def medium(boundary, density):
+        return {"type": "ConstantMedium", "boundary": boundary, "density": density, "phase_func": "I"}
+
+    scene = {
+        "Logistics": {"resolution_x": 8, "resolution_y": 8, "samples": 1, "use_importance_sampling": True},
+        "Camera": {"position": [0, 0, 1], "look_at": [0, 0, 0], "up": [0, 1, 0], "fov": 90, "aspect_ratio": 1, "aperture": 0.1, "focus_distance": 1},
+        "Textures": {"T": {"type": "Constant", "color": [1, 1, 1]}, "P": {"type": "Image", "image_path": "a.png"}, "N": {"type": "Noise", "scale": 2.0},
+                     "U": {"type": "Turbulence", "scale": 1.0, "depth": 3, "omega": 0.5},
+                     "C": {"type": "Checker", "repeat": 4.0, "odd": {"type": "Constant", "color": [1, 1, 1]},
+                           "even": {"type": "Checker", "repeat": 2, "odd": {"type": "Image", "image_path": "a.png"}, "even": {"type": "Test"}}}},
+        "Materials": {"M": {"type": "Lambert", "albedo": "C", "bump_map": "N"}, "I": {"type": "Isotropic", "albedo": "U"},
+                      "G": {"type": "Dielectric", "refractive_index": 1.5}, "L": {"type": "DiffuseLight", "emission": "T"},
+                      "K": {"type": "Metal", "albedo": "P", "roughness": 0.2}},
+        "Aggregate": "BVH",
+        "Shapes": [ball, {"type": "Sphere", "radius": 1, "material": "G"},
+                   {"type": "Mesh", "file_path": "m.obj", "enable_backface_culling": False, "material": "L", "transform": {"translate": [0, 2, 0]}},
+                   medium(medium(dict(ball), 1.0), 2.0),
+                   medium({"type": "Mesh", "file_path": "t.obj", "enable_backface_culling": True, "material": "K"}, 0.5)]}
+    (tmp_path / "s.json").write_text(json.dumps(scene, indent=1))
+    exe = str(tmp_path / "fuzz_scene_loader")
+    host = os.path.join(ROOT, "rust_raytracer_amd", "csrc", "host")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined",
+                           "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "fuzz_scene_loader.cpp")]
+                          + [os.path.join(host, f) for f in ("scene_json.cpp", "scene_host.cpp", "image_io.cpp", "image_codecs.cpp")]
+                          + [os.path.join(ROOT, "rust_raytracer_amd", "csrc", "rrt_error.cpp"), "-lz", "-o", exe])
+    env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=0")
+    r = subprocess.run([exe, str(tmp_path / "s.json"), str(tmp_path / "m.obj")], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "fuzz ok" in r.stdout
+
+
 def test_scene_description_whose_links_are_no_tree_is_refused():
     """rrt_scene_create validates a description before it touches the device (so this needs no GPU): a node with two parents,
     a node no parent names, a child index out of range and a slot range past the end are all refused with a message."""
