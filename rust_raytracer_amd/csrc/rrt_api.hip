@@ -159,7 +159,11 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
 #define RRT_POOL_WAVES 4
 #endif
 constexpr uint32_t kPool = RRT_POOL;    // paths per wave: 15 x 128 x 4 B = 7.5 KB; with the query's work area 9.5 KB: four waves per SIMD
-constexpr uint32_t kPoolSiftCap = 192;  // candidate list of the sifting query: flushed early beyond 128 candidates (a step lists about 110)
+#ifndef RRT_DIRECT_MAX
+#define RRT_DIRECT_MAX 2
+#endif
+constexpr uint32_t kDirectMax = RRT_DIRECT_MAX;  // spheres / media per leaf up to which the sifting query tests them lane by lane instead of in dense groups
+constexpr uint32_t kPoolSiftCap = 320;  // candidate list of the sifting query: flushed early beyond 256 candidates (a step lists about 110)
 constexpr uint32_t kPoolWaves = RRT_POOL_WAVES;  // waves per SIMD the LDS request leaves room for
 // P_PDF_T: the cosine lobe's density of a pending bounce on the way from shading to the query, the hit distance on the way back
 // P_HIT: 0 for a miss, else bit 0 = negative determinant, bits 1..25 slot + 1, bits 26..31 the light the light-or-lobe draw chose
@@ -168,7 +172,7 @@ constexpr uint32_t kPoolMaxLights = 64;
 enum : uint32_t { C_FREE = 0, C_TRACE = 1, C_GEN = 2, C_LTRI = 3, C_LCS = 4, kClasses = 5 };
 // P_META: bits 0..2 class, 3 a diffuse bounce's density is pending, 4 the light-or-lobe draw chose a light, 5..12 depth, 13..31 sample
 constexpr uint32_t kPoolMaxDepth = 255, kPoolMaxSamples = 1u << 19;
-constexpr size_t kPoolBytesPerWave = sift_bytes(kPoolSiftCap) + kHarvestBytesPerWave + (size_t)kPoolFields * kPool * 4;
+constexpr size_t pool_bytes_per_wave(bool harvest) { return sift_bytes(kPoolSiftCap) + (harvest ? kHarvestBytesPerWave : 0u) + (size_t)kPoolFields * kPool * 4; }
 
 template <int AABB_MODE, uint32_t FEAT, bool HARVEST>
 __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters,
@@ -178,7 +182,7 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
     const uint32_t lane = threadIdx.x;
     uint32_t* stack = lds_stack + lane;
     unsigned char* area = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
-    uint32_t* pool = (uint32_t*)(area + sift_bytes(kPoolSiftCap) + kHarvestBytesPerWave);
+    uint32_t* pool = (uint32_t*)(area + sift_bytes(kPoolSiftCap) + (HARVEST ? kHarvestBytesPerWave : 0u));
     uint32_t* list = (uint32_t*)(area + 64 * 8);  // the step's slot list lives where the query will keep its candidate list: read before that
 #define POOL(f, slot) pool[(f) * kPool + (slot)]
     for (uint32_t s = lane; s < kPool; s += 64u) POOL(P_META, s) = C_FREE;
@@ -801,7 +805,7 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         if (!harvest) std::fill(light_of_slot.begin(), light_of_slot.end(), 0u);
         s->harvest = harvest;
         const bool clean = desc->aggregate_kind == RRT_AGGREGATE_BVH_CLEAN;
-        auto emit = [&](uint32_t ia, uint32_t ib, bool has_b) {  // ia < ib: A precedes B in leaf order
+        auto emit = [&](uint32_t ia, uint32_t ib, bool has_b, bool direct = false) {  // ia < ib: A precedes B in leaf order
             if (clean && has_b && desc->slots[ib].prim < desc->slots[ia].prim) std::swap(ia, ib);  // clean trees: A first in SCENE order
             const rrt_slot& A = desc->slots[ia];
             const rrt_slot& B = desc->slots[has_b ? ib : ia];
@@ -828,7 +832,7 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                 }
             }
             const bool lit = light_of_slot[ia] != 0u || (has_b && light_of_slot[ib] != 0u);
-            const float inter[8] = {box[0], box[4], box[1], box[5], box[2], box[6], put_u(lit ? 1u : 0u), 0.0f};  // (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, lit)
+            const float inter[8] = {box[0], box[4], box[1], box[5], box[2], box[6], put_u(lit ? 1u : 0u), put_u(direct ? 1u : 0u)};  // (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, lit, direct)
             pairs.insert(pairs.end(), inter, inter + 8);
         };
         auto half_area = [](const float* b) {
@@ -846,8 +850,12 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             tri.clear();
             for (uint32_t k = 0; k < count; ++k)
                 if (RRT_INFO_KIND(desc->slots[first + k].info) == RRT_KIND_TRIANGLE) tri.push_back(first + k);
-                else emit(first + k, first + k, false);
             const uint32_t nt = (uint32_t)tri.size();
+            // spheres and media get records of their own; a leaf with only one or two of them (too few to fill a dense group of the
+            // sifting query) has them tested by the rays' own lanes (closest_hit_sift)
+            const bool direct = count - nt <= kDirectMax;
+            for (uint32_t k = 0; k < count; ++k)
+                if (RRT_INFO_KIND(desc->slots[first + k].info) != RRT_KIND_TRIANGLE) emit(first + k, first + k, false, direct);
             boxes.resize((size_t)nt * 8);
             for (uint32_t i = 0; i < nt; ++i) pair_box(desc, tri[i], 1, pad, &boxes[(size_t)i * 8]);
             // gain of sharing a record = area of the two boxes minus the area of their union (a ray meets a box about in
@@ -1417,7 +1425,7 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
             ta.n_items = (uint32_t)items;
             const dim3 pgrid((unsigned)(items < s->wave_places ? items : s->wave_places));
             if (s->harvest) ta.stack_depth = 0;  // a single leaf: the walk never pushes
-            const size_t plds = (size_t)kTraceBlock * ta.stack_depth * sizeof(uint32_t) + kPoolBytesPerWave;
+            const size_t plds = (size_t)kTraceBlock * ta.stack_depth * sizeof(uint32_t) + pool_bytes_per_wave(s->harvest);
             HIP_TRY(hipMemsetAsync(s->d_items, 0, sizeof(uint32_t), st));
 #define RRT_LAUNCH_POOL(MODE, FEAT, HARV) hipLaunchKernelGGL((k_trace_pool<MODE, FEAT, HARV>), pgrid, dim3(kTraceBlock), plds, st, s->d, ta, pass_slab, cnt, s->d_items)
 #define RRT_PICK_POOL(MODE)                                                  \
@@ -1819,6 +1827,14 @@ extern "C" int rrt_profile_read_pool(uint64_t* out18) {
     HIP_TRY(hipMemcpyFromSymbol(out18, HIP_SYMBOL(g_pool_prof), 3 * kClasses * 8));
     uint64_t zero[3 * kClasses] = {0};
     HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_pool_prof), zero, 3 * kClasses * 8));
+    return RRT_OK;
+}
+// profiling build only: reads and clears the sifting query's list-size histogram and cycle split (20 values)
+extern "C" int rrt_profile_read_sift(uint64_t* out20) {
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpyFromSymbol(out20, HIP_SYMBOL(g_sift_hist), 160));
+    uint64_t zero[20] = {0};
+    HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(g_sift_hist), zero, 160));
     return RRT_OK;
 }
 // profiling build only: reads and clears the traversal counters

@@ -226,12 +226,19 @@ RRT_DEV bool box_overlap(f3 lo, f3 hi, f3 o, f3 inv, float t_min, float t_max) {
 // with (plane - origin) * inv the result moves by a few ulps of |origin * inv|, i.e. by a few 1e-7 of the origin's
 // coordinate in space, far inside the padding of the boxes (1e-5 of the scene's extent, camera position included).
 typedef float v2f_ __attribute__((ext_vector_type(2)));
+// v_min_f32 as the hardware does it (IEEE mode: a signalling NaN operand is quieted by the instruction itself).  The compiler's own
+// minimum first canonicalises an operand it knows nothing about - one more instruction per box test for the loop-invariant bound.
+RRT_DEV float min_as_is(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 RRT_DEV bool pair_box_overlap(v2f_ x, v2f_ y, v2f_ z, f3 inv, f3 noi, float t_min, float t_max) {
     const v2f_ tx = __builtin_elementwise_fma(x, v2f_{inv.x, inv.x}, v2f_{noi.x, noi.x});
     const v2f_ ty = __builtin_elementwise_fma(y, v2f_{inv.y, inv.y}, v2f_{noi.y, noi.y});
     const v2f_ tz = __builtin_elementwise_fma(z, v2f_{inv.z, inv.z}, v2f_{noi.z, noi.z});
     const float t_near = __builtin_fmaxf(__builtin_fmaxf(__builtin_fminf(tx.x, tx.y), __builtin_fminf(ty.x, ty.y)), __builtin_fmaxf(__builtin_fminf(tz.x, tz.y), t_min));
-    const float t_far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)), __builtin_fminf(__builtin_fmaxf(tz.x, tz.y), t_max));
+    const float t_far = __builtin_fminf(__builtin_fminf(__builtin_fmaxf(tx.x, tx.y), __builtin_fmaxf(ty.x, ty.y)), min_as_is(__builtin_fmaxf(tz.x, tz.y), t_max));
     return t_near <= t_far;
 }
 

@@ -13,13 +13,32 @@ namespace rrt {
 static __device__ unsigned long long g_prof[8];       // stream kernels: node visits, pair tests, node steps, leaf steps, cycles shade / walk / leaf, shade phases
                                                       // sifting query ([4..7], shallow-tree kernels): filter steps, items, dense groups, phases
 static __device__ unsigned long long g_pool_prof[15]; // k_trace_pool, per kind of work: steps | paths served | cycles
+static __device__ unsigned long long g_sift_hist[20]; // sifting query: flushes by list size in sixteenths of 256 ([0..15], last = more), cycles sifting [16] and in dense groups [17], lanes with a ray [18]
 
 struct SiftProbe {
-    unsigned long long filter = 0, items = 0, groups = 0, phases = 0;
+    unsigned long long filter = 0, items = 0, groups = 0, phases = 0, cyc_sift = 0, cyc_dense = 0, owners = 0;
+    unsigned long long tick = 0;
+    uint32_t hist[16] = {};
     __device__ void pair_tested() { filter += 1; }
+    __device__ void sift_begins(uint32_t n_owners) {
+        tick = __builtin_readcyclecounter();
+        owners += n_owners;
+    }
     __device__ void flushed(uint32_t n_items) {
+        const unsigned long long now = __builtin_readcyclecounter();
+        cyc_sift += now - tick;
+        tick = now;
         items += n_items;
         groups += (n_items + 63u) / 64u;
+        const uint32_t b = n_items / 16u < 15u ? n_items / 16u : 15u;
+#pragma unroll
+        for (uint32_t i = 0; i < 16; ++i)
+            if (b == i) hist[i] += 1;
+    }
+    __device__ void dense_done() {
+        const unsigned long long now = __builtin_readcyclecounter();
+        cyc_dense += now - tick;
+        tick = now;
     }
     __device__ void phase_done() { phases += 1; }
     __device__ void store(uint32_t lane) {
@@ -28,6 +47,10 @@ struct SiftProbe {
         atomicAdd(&g_prof[5], items);
         atomicAdd(&g_prof[6], groups);
         atomicAdd(&g_prof[7], phases);
+        for (uint32_t i = 0; i < 16; ++i) atomicAdd(&g_sift_hist[i], (unsigned long long)hist[i]);
+        atomicAdd(&g_sift_hist[16], cyc_sift);
+        atomicAdd(&g_sift_hist[17], cyc_dense);
+        atomicAdd(&g_sift_hist[18], owners);
     }
 };
 
@@ -100,6 +123,8 @@ struct StreamProbe {
 #else
 struct SiftProbe {
     __device__ void pair_tested() {}
+    __device__ void sift_begins(uint32_t) {}
+    __device__ void dense_done() {}
     __device__ void flushed(uint32_t) {}
     __device__ void phase_done() {}
     __device__ void store(uint32_t) {}

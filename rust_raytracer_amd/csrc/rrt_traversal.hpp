@@ -639,6 +639,8 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             for (uint32_t i = 0; i < kHarvestLights; ++i) light_t[lane * kHarvestLights + i] = -1.0f;
         uint32_t n_items = 0;
         unsigned long long todo = waiting;
+        unsigned long long direct_best = ~0ull;  // this phase's nearest directly tested primitive, as the dense groups' key
+        probe.sift_begins((uint32_t)__popcll(waiting));
         while (todo != 0ull) {
             // the paused lanes are grouped by leaf (one group for the single-leaf trees of the small scenes)
             const int leader = __ffsll((long long)todo) - 1;
@@ -647,15 +649,40 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             const bool mine = pending && first_pair == leaf_first;
             // Lanes that take no part get an upper bound of -infinity, which no box interval reaches: the loop then runs the same
             // arithmetic in every lane, without masking.  HARVEST: a lane whose ray the leaf's box test kept out only collects light
-            // distances, so for it that bound also applies to every pair without a light's primitive.
-            const float upper_all = mine ? h.t : -__builtin_inff();
-            const float upper_inside = mine && !lights_only ? h.t : -__builtin_inff();
+            // distances, so it is struck from the result of every pair without a light's primitive (a scalar mask operation).
+            float upper = mine ? h.t : -__builtin_inff();
+            asm("" : "+v"(upper));  // (keeps the choice out of the loop: the compiler would redo it after every box test)
+            const unsigned long long lights_only_lanes = HARVEST ? RRT_BALLOT(mine && lights_only) : 0ull;
             for (uint32_t k = 0; k < leaf_pairs; ++k) {
                 const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
-                const v4f bx = rec[6], bz = rec[7];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, holds a light's primitive, -)
-                const float upper = HARVEST && __float_as_uint(bz.z) == 0u ? upper_inside : upper_all;  // a wave-uniform choice
-                const bool pass = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
-                const unsigned long long bal = RRT_BALLOT(pass);
+                const v4f bx = rec[6], bz = rec[7];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, holds a light's primitive, tested directly)
+                const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
+                unsigned long long bal = RRT_BALLOT(box_met);
+                if (HARVEST && __float_as_uint(bz.z) == 0u) bal &= ~lights_only_lanes;  // a wave-uniform choice
+                const bool pass = __builtin_amdgcn_inverse_ballot_w64(bal);
+                if ((FEAT & (F_SPHERE | F_MEDIUM)) && __float_as_uint(bz.w) != 0u) {
+                    // A record the host marked for direct testing: a single sphere or medium in a leaf that has only one or two of them.
+                    // Too few of a kind to fill a dense group, so each lane whose ray meets the box tests its own ray here, with the
+                    // record in scalar registers; the answer competes with the dense groups' by the same (distance, slot) key.
+                    if (pass) {
+                        const v4f q4 = rec[4], q5 = rec[5];
+                        Hit hh;
+                        hh.slot = -1;
+                        hh.t = t_max;
+                        hh.u = hh.v = hh.det = 0.0f;
+                        test_slot<FEAT>(sc, __float_as_uint(q5.x), r, t_min, key, depth, hh);
+                        if (hh.slot >= 0) {
+                            const uint32_t light_a = HARVEST ? RRT_PAIR_LIGHT(__float_as_uint(q4.z)) : 0u;
+                            if (HARVEST && light_a != 0u) light_t[lane * kHarvestLights + light_a - 1u] = hh.t;  // Sphere::pdf, shape.rs:142
+                            if (!(HARVEST && lights_only)) {
+                                const unsigned long long cand = ((unsigned long long)ord_bits(hh.t) << 32) | (unsigned long long)(((uint32_t)hh.slot + 1u) << 1);
+                                direct_best = cand < direct_best ? cand : direct_best;
+                            }
+                        }
+                    }
+                    probe.pair_tested();
+                    continue;
+                }
                 if (pass) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                     if (HARVEST) items[n_items + rank] = ((leaf_first + k) << 7) | (lights_only ? 64u : 0u) | lane;
@@ -666,6 +693,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                 if (n_items > CAP - 64u) {
                     probe.flushed(n_items);
                     sift_flush<FEAT, HARVEST, CAP>(sc, r, t_min, t_max, key, depth, items, n_items, best);
+                    probe.dense_done();
                     n_items = 0;
                 }
             }
@@ -674,10 +702,12 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
         probe.flushed(n_items);
         probe.phase_done();
         sift_flush<FEAT, HARVEST, CAP>(sc, r, t_min, t_max, key, depth, items, n_items, best);
+        probe.dense_done();
         if (pending) {
             if (HARVEST)
                 for (uint32_t i = 0; i < kHarvestLights; ++i) harvest[i] = light_t[lane * kHarvestLights + i];
-            const unsigned long long w = best[lane];
+            unsigned long long w = best[lane];
+            if ((FEAT & (F_SPHERE | F_MEDIUM)) && direct_best < w) w = direct_best;
             const uint32_t low = (uint32_t)w;
             if (low != 0u) {
                 h.t = ord_float((uint32_t)(w >> 32));

@@ -23,3 +23,10 @@ for i, nm in enumerate(["FREE", "TRACE", "GEN", "LTRI", "LCS"]):
     if steps[i]:
         print("%-6s steps %10d  paths/step %5.1f  cycles %5.1f %%  cycles/step %8.0f" % (nm, steps[i], lanes[i] / steps[i], 100 * cyc[i] / cyc.sum(), cyc[i] / steps[i]))
 print("mean paths per step %.1f; steps per ray %.3f" % (lanes.sum() / steps.sum(), steps.sum() / c[0]))
+h = np.zeros(20, dtype=np.uint64)
+rrt.lib().rrt_profile_read_sift(ctypes.c_void_p(h.ctypes.data))
+h = h.astype(float)
+if h[:16].sum():
+    print("candidate lists by size (items, share of queries): " + "  ".join("%d-%d: %.1f%%" % (16 * i, 16 * i + 15, 100 * h[i] / h[:16].sum()) for i in range(16) if h[i]))
+    print("query cycles: sifting %.1f %%, dense groups %.1f %%; rays per query %.1f; cycles per query: sifting %.0f, dense %.0f" % (
+        100 * h[16] / (h[16] + h[17]), 100 * h[17] / (h[16] + h[17]), h[18] / h[:16].sum(), h[16] / h[:16].sum(), h[17] / h[:16].sum()))
