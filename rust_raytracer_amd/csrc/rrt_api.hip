@@ -160,10 +160,13 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
 #endif
 constexpr uint32_t kPool = RRT_POOL;    // paths per wave: 15 x 128 x 4 B = 7.5 KB; with the query's work area 9.5 KB: four waves per SIMD
 #ifndef RRT_DIRECT_MAX
-#define RRT_DIRECT_MAX 2
+#define RRT_DIRECT_MAX 1
 #endif
 constexpr uint32_t kDirectMax = RRT_DIRECT_MAX;  // spheres / media per leaf up to which the sifting query tests them lane by lane instead of in dense groups
-constexpr uint32_t kPoolSiftCap = 320;  // candidate list of the sifting query: flushed early beyond 256 candidates (a step lists about 110)
+#ifndef RRT_POOL_SIFT_CAP
+#define RRT_POOL_SIFT_CAP 320
+#endif
+constexpr uint32_t kPoolSiftCap = RRT_POOL_SIFT_CAP;  // candidate list of the sifting query: flushed early beyond 256 candidates (a step lists about 110)
 constexpr uint32_t kPoolWaves = RRT_POOL_WAVES;  // waves per SIMD the LDS request leaves room for
 // P_PDF_T: the cosine lobe's density of a pending bounce on the way from shading to the query, the hit distance on the way back
 // P_HIT: 0 for a miss, else bit 0 = negative determinant, bits 1..25 slot + 1, bits 26..31 the light the light-or-lobe draw chose
@@ -851,8 +854,9 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             for (uint32_t k = 0; k < count; ++k)
                 if (RRT_INFO_KIND(desc->slots[first + k].info) == RRT_KIND_TRIANGLE) tri.push_back(first + k);
             const uint32_t nt = (uint32_t)tri.size();
-            // spheres and media get records of their own; a leaf with only one or two of them (too few to fill a dense group of the
-            // sifting query) has them tested by the rays' own lanes (closest_hit_sift)
+            // spheres and media get records of their own, at the front of the leaf; a leaf with only one of them (too few to fill a
+            // dense group of the sifting query; with two, Materials.json renders 1.5 % slower) has it tested by the rays' own lanes
+            // (closest_hit_sift)
             const bool direct = count - nt <= kDirectMax;
             for (uint32_t k = 0; k < count; ++k)
                 if (RRT_INFO_KIND(desc->slots[first + k].info) != RRT_KIND_TRIANGLE) emit(first + k, first + k, false, direct);

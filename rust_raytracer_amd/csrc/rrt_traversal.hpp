@@ -653,17 +653,17 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             float upper = mine ? h.t : -__builtin_inff();
             asm("" : "+v"(upper));  // (keeps the choice out of the loop: the compiler would redo it after every box test)
             const unsigned long long lights_only_lanes = HARVEST ? RRT_BALLOT(mine && lights_only) : 0ull;
-            for (uint32_t k = 0; k < leaf_pairs; ++k) {
-                const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
-                const v4f bx = rec[6], bz = rec[7];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, holds a light's primitive, tested directly)
-                const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
-                unsigned long long bal = RRT_BALLOT(box_met);
-                if (HARVEST && __float_as_uint(bz.z) == 0u) bal &= ~lights_only_lanes;  // a wave-uniform choice
-                const bool pass = __builtin_amdgcn_inverse_ballot_w64(bal);
-                if ((FEAT & (F_SPHERE | F_MEDIUM)) && __float_as_uint(bz.w) != 0u) {
-                    // A record the host marked for direct testing: a single sphere or medium in a leaf that has only one or two of them.
-                    // Too few of a kind to fill a dense group, so each lane whose ray meets the box tests its own ray here, with the
-                    // record in scalar registers; the answer competes with the dense groups' by the same (distance, slot) key.
+            uint32_t k = 0;
+            if (FEAT & (F_SPHERE | F_MEDIUM)) {
+                // Records the host marked for direct testing come first in their leaf: a single sphere or medium in a leaf that has no
+                // other.  Too few of a kind to fill a dense group, so each lane whose ray meets the box tests its own ray here, with
+                // the record in scalar registers; the answer competes with the dense groups' by the same (distance, slot) key.
+                for (; k < leaf_pairs; ++k) {
+                    const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
+                    const v4f bx = rec[6], bz = rec[7];
+                    if (__float_as_uint(bz.w) == 0u) break;
+                    const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
+                    const bool pass = box_met && !(HARVEST && lights_only && __float_as_uint(bz.z) == 0u);
                     if (pass) {
                         const v4f q4 = rec[4], q5 = rec[5];
                         Hit hh;
@@ -681,8 +681,15 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                         }
                     }
                     probe.pair_tested();
-                    continue;
                 }
+            }
+            for (; k < leaf_pairs; ++k) {
+                const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
+                const v4f bx = rec[6], bz = rec[7];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, holds a light's primitive, tested directly)
+                const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
+                unsigned long long bal = RRT_BALLOT(box_met);
+                if (HARVEST && __float_as_uint(bz.z) == 0u) bal &= ~lights_only_lanes;  // a wave-uniform choice
+                const bool pass = __builtin_amdgcn_inverse_ballot_w64(bal);
                 if (pass) {
                     const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
                     if (HARVEST) items[n_items + rank] = ((leaf_first + k) << 7) | (lights_only ? 64u : 0u) | lane;
