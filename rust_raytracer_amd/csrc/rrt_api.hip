@@ -857,7 +857,8 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             // spheres and media get records of their own, at the front of the leaf; a leaf with only one of them (too few to fill a
             // dense group of the sifting query; with two, Materials.json renders 1.5 % slower) has it tested by the rays' own lanes
             // (closest_hit_sift)
-            const bool direct = count - nt <= kDirectMax;
+            const bool shallow = !clean && desc->n_nodes <= kDeepTreeNodes;  // the sifting query's trees
+            const bool direct = shallow && count - nt != 0u && count - nt <= kDirectMax;
             for (uint32_t k = 0; k < count; ++k)
                 if (RRT_INFO_KIND(desc->slots[first + k].info) != RRT_KIND_TRIANGLE) emit(first + k, first + k, false, direct);
             boxes.resize((size_t)nt * 8);
@@ -893,6 +894,7 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             }
             n.a = first_pair;
             n.b = RRT_LEAF_FLAG | ((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair);
+            if (direct) n.b |= kLeafDirect;  // (a shallow tree holds at most 2^25 pair records: the bit is free)
         }
         const std::vector<float> tb = tight_boxes(desc);
         if (clean) {

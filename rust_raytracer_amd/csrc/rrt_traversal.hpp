@@ -488,6 +488,7 @@ RRT_DEV void triangle_uvdet(f3 v0, f3 e1, f3 e2, const Ray& r, float* u, float* 
 // reports, per light, the distance at which the ray meets the light's own primitive (any distance in (t_min, t_max), whether
 // or not something nearer hides it, and whether or not the leaf's box test let the ray in: Shape::pdf asks the shape, not
 // the tree), and the caller finishes the previous bounce's throughput from that.  Same tests, same numbers, run once.
+constexpr uint32_t kLeafDirect = 0x40000000u;  // in a shallow tree's leaf node, beside the pair count: the leaf begins with directly tested records
 constexpr uint32_t kSiftCap = 512;  // items the candidate list holds (the CAP template argument below; a caller short of LDS passes less)
 constexpr uint32_t kHarvestLights = 3;
 constexpr uint32_t sift_bytes(uint32_t cap) { return 64 * 8 + cap * 4; }
@@ -645,7 +646,8 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             // the paused lanes are grouped by leaf (one group for the single-leaf trees of the small scenes)
             const int leader = __ffsll((long long)todo) - 1;
             const uint32_t leaf_first = (uint32_t)__builtin_amdgcn_readlane((int)first_pair, leader);
-            const uint32_t leaf_pairs = (uint32_t)__builtin_amdgcn_readlane((int)n_pairs, leader);
+            const uint32_t leaf_word = (uint32_t)__builtin_amdgcn_readlane((int)n_pairs, leader);
+            const uint32_t leaf_pairs = leaf_word & ~kLeafDirect;
             const bool mine = pending && first_pair == leaf_first;
             // Lanes that take no part get an upper bound of -infinity, which no box interval reaches: the loop then runs the same
             // arithmetic in every lane, without masking.  HARVEST: a lane whose ray the leaf's box test kept out only collects light
@@ -654,9 +656,9 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             asm("" : "+v"(upper));  // (keeps the choice out of the loop: the compiler would redo it after every box test)
             const unsigned long long lights_only_lanes = HARVEST ? RRT_BALLOT(mine && lights_only) : 0ull;
             uint32_t k = 0;
-            if (FEAT & (F_SPHERE | F_MEDIUM)) {
-                // Records the host marked for direct testing come first in their leaf: a single sphere or medium in a leaf that has no
-                // other.  Too few of a kind to fill a dense group, so each lane whose ray meets the box tests its own ray here, with
+            if ((FEAT & (F_SPHERE | F_MEDIUM)) && (leaf_word & kLeafDirect) != 0u) {
+                // Records the host marked for direct testing come first in their leaf (which carries a mark of its own, so that other
+                // leaves do not pay for a look): a single sphere or medium in a leaf that has no other.  Too few of a kind to fill a dense group, so each lane whose ray meets the box tests its own ray here, with
                 // the record in scalar registers; the answer competes with the dense groups' by the same (distance, slot) key.
                 for (; k < leaf_pairs; ++k) {
                     const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
