@@ -159,10 +159,6 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
 #define RRT_POOL_WAVES 4
 #endif
 constexpr uint32_t kPool = RRT_POOL;    // paths per wave: 15 x 128 x 4 B = 7.5 KB; with the query's work area 9.5 KB: four waves per SIMD
-#ifndef RRT_DIRECT_MAX
-#define RRT_DIRECT_MAX 1
-#endif
-constexpr uint32_t kDirectMax = RRT_DIRECT_MAX;  // spheres / media per leaf up to which the sifting query tests them lane by lane instead of in dense groups
 #ifndef RRT_POOL_SIFT_CAP
 #define RRT_POOL_SIFT_CAP 320
 #endif
@@ -818,7 +814,7 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         if (!harvest) std::fill(light_of_slot.begin(), light_of_slot.end(), 0u);
         s->harvest = harvest;
         const bool clean = desc->aggregate_kind == RRT_AGGREGATE_BVH_CLEAN;
-        auto emit = [&](uint32_t ia, uint32_t ib, bool has_b, bool direct = false) {  // ia < ib: A precedes B in leaf order
+        auto emit = [&](uint32_t ia, uint32_t ib, bool has_b) {  // ia < ib: A precedes B in leaf order
             if (clean && has_b && desc->slots[ib].prim < desc->slots[ia].prim) std::swap(ia, ib);  // clean trees: A first in SCENE order
             const rrt_slot& A = desc->slots[ia];
             const rrt_slot& B = desc->slots[has_b ? ib : ia];
@@ -845,7 +841,8 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                 }
             }
             const bool lit = light_of_slot[ia] != 0u || (has_b && light_of_slot[ib] != 0u);
-            const float inter[8] = {box[0], box[4], box[1], box[5], box[2], box[6], put_u(lit ? 1u : 0u), put_u(direct ? 1u : 0u)};  // (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, lit, direct)
+            const float lit_lanes = put_u(lit ? kPairLitMask : 0u);
+            const float inter[8] = {box[0], box[4], box[1], box[5], box[2], box[6], lit_lanes, lit_lanes};  // (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, lane mask in two words)
             pairs.insert(pairs.end(), inter, inter + 8);
         };
         auto half_area = [](const float* b) {
@@ -864,13 +861,13 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             for (uint32_t k = 0; k < count; ++k)
                 if (RRT_INFO_KIND(desc->slots[first + k].info) == RRT_KIND_TRIANGLE) tri.push_back(first + k);
             const uint32_t nt = (uint32_t)tri.size();
-            // spheres and media get records of their own, at the front of the leaf; a leaf with only one of them (too few to fill a
-            // dense group of the sifting query; with two, Materials.json renders 1.5 % slower) has it tested by the rays' own lanes
-            // (closest_hit_sift)
+            // spheres and media get records of their own, at the front of the leaf; a leaf with exactly one of them (too few to fill
+            // a dense group of the sifting query; with two, Materials.json renders 1.5 % slower) has it tested by the rays' own lanes
+            // (closest_hit_sift), and says so in its node
             const bool shallow = !clean && desc->n_nodes <= kDeepTreeNodes;  // the sifting query's trees
-            const bool direct = shallow && count - nt != 0u && count - nt <= kDirectMax;
+            const bool direct = shallow && count - nt == 1u;
             for (uint32_t k = 0; k < count; ++k)
-                if (RRT_INFO_KIND(desc->slots[first + k].info) != RRT_KIND_TRIANGLE) emit(first + k, first + k, false, direct);
+                if (RRT_INFO_KIND(desc->slots[first + k].info) != RRT_KIND_TRIANGLE) emit(first + k, first + k, false);
             boxes.resize((size_t)nt * 8);
             for (uint32_t i = 0; i < nt; ++i) pair_box(desc, tri[i], 1, pad, &boxes[(size_t)i * 8]);
             // gain of sharing a record = area of the two boxes minus the area of their union (a ray meets a box about in

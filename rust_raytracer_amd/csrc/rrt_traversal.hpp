@@ -488,7 +488,11 @@ RRT_DEV void triangle_uvdet(f3 v0, f3 e1, f3 e2, const Ray& r, float* u, float* 
 // reports, per light, the distance at which the ray meets the light's own primitive (any distance in (t_min, t_max), whether
 // or not something nearer hides it, and whether or not the leaf's box test let the ray in: Shape::pdf asks the shape, not
 // the tree), and the caller finishes the previous bounce's throughput from that.  Same tests, same numbers, run once.
-constexpr uint32_t kLeafDirect = 0x40000000u;  // in a shallow tree's leaf node, beside the pair count: the leaf begins with directly tested records
+constexpr uint32_t kLeafDirect = 0x40000000u;  // in a shallow tree's leaf node, beside the pair count: the leaf's FIRST record is tested directly
+// A pair record's last two words are a lane mask for the harvesting query: all ones when the pair holds a light's primitive (lanes that
+// only collect light distances stay), zero when it does not (they are struck) - two words, so that the scalar unit takes them as one
+// 64-bit operand.
+constexpr uint32_t kPairLitMask = 0xffffffffu;
 constexpr uint32_t kSiftCap = 512;  // items the candidate list holds (the CAP template argument below; a caller short of LDS passes less)
 constexpr uint32_t kHarvestLights = 3;
 constexpr uint32_t sift_bytes(uint32_t cap) { return 64 * 8 + cap * 4; }
@@ -655,47 +659,50 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             float upper = mine ? h.t : -__builtin_inff();
             asm("" : "+v"(upper));  // (keeps the choice out of the loop: the compiler would redo it after every box test)
             const unsigned long long lights_only_lanes = HARVEST ? RRT_BALLOT(mine && lights_only) : 0ull;
+            const unsigned long long whole_query_lanes = ~lights_only_lanes;
             uint32_t k = 0;
             if ((FEAT & (F_SPHERE | F_MEDIUM)) && (leaf_word & kLeafDirect) != 0u) {
-                // Records the host marked for direct testing come first in their leaf (which carries a mark of its own, so that other
-                // leaves do not pay for a look): a single sphere or medium in a leaf that has no other.  Too few of a kind to fill a dense group, so each lane whose ray meets the box tests its own ray here, with
-                // the record in scalar registers; the answer competes with the dense groups' by the same (distance, slot) key.
-                for (; k < leaf_pairs; ++k) {
-                    const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
-                    const v4f bx = rec[6], bz = rec[7];
-                    if (__float_as_uint(bz.w) == 0u) break;
-                    const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
-                    const bool pass = box_met && !(HARVEST && lights_only && __float_as_uint(bz.z) == 0u);
-                    if (pass) {
-                        const v4f q4 = rec[4], q5 = rec[5];
-                        Hit hh;
-                        hh.slot = -1;
-                        hh.t = t_max;
-                        hh.u = hh.v = hh.det = 0.0f;
-                        test_slot<FEAT>(sc, __float_as_uint(q5.x), r, t_min, key, depth, hh);
-                        if (hh.slot >= 0) {
-                            const uint32_t light_a = HARVEST ? RRT_PAIR_LIGHT(__float_as_uint(q4.z)) : 0u;
-                            if (HARVEST && light_a != 0u) light_t[lane * kHarvestLights + light_a - 1u] = hh.t;  // Sphere::pdf, shape.rs:142
-                            if (!(HARVEST && lights_only)) {
-                                const unsigned long long cand = ((unsigned long long)ord_bits(hh.t) << 32) | (unsigned long long)(((uint32_t)hh.slot + 1u) << 1);
-                                direct_best = cand < direct_best ? cand : direct_best;
-                            }
+                // The host marks a leaf whose only sphere or medium stands alone among triangles, and puts that record first.  One of a
+                // kind cannot fill a dense group, so each lane whose ray meets the box tests its own ray here, with the record in scalar
+                // registers; the answer competes with the dense groups' by the same (distance, slot) key.
+                const cv4p rec = cpairs + kPairQuads * leaf_first;
+                const v4f bx = rec[6], bz = rec[7];
+                const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
+                const bool pass = box_met && !(HARVEST && lights_only && __float_as_uint(bz.z) == 0u);
+                if (pass) {
+                    const v4f q4 = rec[4], q5 = rec[5];
+                    Hit hh;
+                    hh.slot = -1;
+                    hh.t = t_max;
+                    hh.u = hh.v = hh.det = 0.0f;
+                    test_slot<FEAT>(sc, __float_as_uint(q5.x), r, t_min, key, depth, hh);
+                    if (hh.slot >= 0) {
+                        const uint32_t light_a = HARVEST ? RRT_PAIR_LIGHT(__float_as_uint(q4.z)) : 0u;
+                        if (HARVEST && light_a != 0u) light_t[lane * kHarvestLights + light_a - 1u] = hh.t;  // Sphere::pdf, shape.rs:142
+                        if (!(HARVEST && lights_only)) {
+                            const unsigned long long cand = ((unsigned long long)ord_bits(hh.t) << 32) | (unsigned long long)(((uint32_t)hh.slot + 1u) << 1);
+                            direct_best = cand < direct_best ? cand : direct_best;
                         }
                     }
-                    probe.pair_tested();
                 }
+                probe.pair_tested();
+                k = 1;
             }
-            for (; k < leaf_pairs; ++k) {
-                const cv4p rec = cpairs + kPairQuads * (leaf_first + k);
-                const v4f bx = rec[6], bz = rec[7];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, holds a light's primitive, tested directly)
+            // (the loop runs on the pair's number and a pointer that moves from box to box: its scalar instructions
+            // count as much as its vector ones - the scalar unit serves a SIMD once in four cycles, the rate at which a SIMD issues
+            // wave-wide vector work)
+            const uint32_t pair_end = leaf_first + leaf_pairs;
+            cv4p box = cpairs + (size_t)kPairQuads * (leaf_first + k) + 6;
+            for (uint32_t pair = leaf_first + k; pair < pair_end; ++pair, box += kPairQuads) {
+                const v4f bx = box[0], bz = box[1];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, lane mask in two words: see kPairLitMask)
                 const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
                 unsigned long long bal = RRT_BALLOT(box_met);
-                if (HARVEST && __float_as_uint(bz.z) == 0u) bal &= ~lights_only_lanes;  // a wave-uniform choice
+                if (HARVEST) bal &= whole_query_lanes | (((unsigned long long)__float_as_uint(bz.w) << 32) | (unsigned long long)__float_as_uint(bz.z));
                 const bool pass = __builtin_amdgcn_inverse_ballot_w64(bal);
-                if (pass) {
-                    const uint32_t rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                    if (HARVEST) items[n_items + rank] = ((leaf_first + k) << 7) | (lights_only ? 64u : 0u) | lane;
-                    else items[n_items + rank] = ((leaf_first + k) << 6) | lane;
+                if (pass) {  // (the prefix count starts from the list's length: the place in the list in two instructions)
+                    const uint32_t place = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, n_items));
+                    if (HARVEST) items[place] = (pair << 7) | (lights_only ? 64u : 0u) | lane;
+                    else items[place] = (pair << 6) | lane;
                 }
                 n_items += (uint32_t)__popcll(bal);
                 probe.pair_tested();
