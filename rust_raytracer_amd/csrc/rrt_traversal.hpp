@@ -691,9 +691,13 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             // (the loop runs on the pair's number and a pointer that moves from box to box: its scalar instructions
             // count as much as its vector ones - the scalar unit serves a SIMD once in four cycles, the rate at which a SIMD issues
             // wave-wide vector work)
-            const uint32_t pair_end = leaf_first + leaf_pairs;
-            cv4p box = cpairs + (size_t)kPairQuads * (leaf_first + k) + 6;
-            for (uint32_t pair = leaf_first + k; pair < pair_end; ++pair, box += kPairQuads) {
+            // `at` = the pair's number times the size of a pair record: the byte offset of its record, and at the same time the pair
+            // field of a list entry (records are 128 bytes; entries hold the pair from bit 7 up when harvesting, from bit 6 otherwise)
+            static_assert(kPairQuads * 16u == 128u, "a list entry's pair field is the record's byte offset");
+            const uint32_t at_end = (leaf_first + leaf_pairs) * 128u;
+            const char* const boxes = (const char*)cpairs + 6 * 16;
+            for (uint32_t at = (leaf_first + k) * 128u; at < at_end; at += 128u) {
+                const cv4p box = (cv4p)(boxes + at);
                 const v4f bx = box[0], bz = box[1];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, lane mask in two words: see kPairLitMask)
                 const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
                 unsigned long long bal = RRT_BALLOT(box_met);
@@ -701,8 +705,8 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                 const bool pass = __builtin_amdgcn_inverse_ballot_w64(bal);
                 if (pass) {  // (the prefix count starts from the list's length: the place in the list in two instructions)
                     const uint32_t place = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, n_items));
-                    if (HARVEST) items[place] = (pair << 7) | (lights_only ? 64u : 0u) | lane;
-                    else items[place] = (pair << 6) | lane;
+                    if (HARVEST) items[place] = at | (lights_only ? 64u : 0u) | lane;
+                    else items[place] = (at >> 1) | lane;
                 }
                 n_items += (uint32_t)__popcll(bal);
                 probe.pair_tested();
