@@ -1058,7 +1058,7 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         }
         // the sifting traversal of shallow trees packs (pair, lane) into 32 bits
         if (!clean && desc->n_nodes <= kDeepTreeNodes && pairs.size() / (4 * kPairQuads) >= (1u << 25))  // (pair number x 128, the record's byte offset, stays below 2^32)
-            return rrt_set_error(RRT_ERR_LIMIT, "a tree of at most 16 nodes (or a List) with more than 2^25 pair records");
+            return rrt_set_error(RRT_ERR_LIMIT, "a tree of at most 16 nodes (or a List) with 2^25 pair records or more");
         UP(pairs, (const float4*)pairs.data(), pairs.size() / 4);
     }
     {
