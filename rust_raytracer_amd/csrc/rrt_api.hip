@@ -903,6 +903,20 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             n.b = RRT_LEAF_FLAG | ((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair);
             if (direct) n.b |= kLeafDirect;  // (a shallow tree holds at most 2^25 pair records: the bit is free)
         }
+        if (!clean && desc->n_nodes <= kDeepTreeNodes) {
+            // the sifting query (shallow trees) reads a pair's box as half-widths and centres: (h.x, c.x, h.y, c.y | h.z, c.z, ...);
+            // a half-width is rounded up past the larger of the two distances, so the stored box contains the padded one
+            for (size_t r = 0; r + 4 * kPairQuads <= pairs.size(); r += 4 * kPairQuads) {
+                float* b = &pairs[r + 24];
+                for (int c = 0; c < 3; ++c) {
+                    const float lo = b[2 * c], hi = b[2 * c + 1];
+                    const float mid = 0.5f * lo + 0.5f * hi;
+                    const float half = std::nextafter(std::fmax(hi - mid, mid - lo), std::numeric_limits<float>::infinity());
+                    b[2 * c] = half;
+                    b[2 * c + 1] = mid;
+                }
+            }
+        }
         const std::vector<float> tb = tight_boxes(desc);
         if (clean) {
             // Inner nodes only, 64 bytes each, with up to FOUR children (see walk_step).  The children's primitive boxes are stored

@@ -588,12 +588,14 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
     unsigned long long* best = (unsigned long long*)area;
     uint32_t* items = (uint32_t*)(area + 64 * 8);
     const f3 inv = mk3(exact_rcp(r.d.x), exact_rcp(r.d.y), exact_rcp(r.d.z));  // = 1.0f / r.d, bit for bit (see exact_rcp)
-    // for the pair boxes: plane * finv + noi (see pair_box_overlap); an axis whose product origin * inv is not finite (zero or
+    // for the pair boxes: centre * finv + noi (see pair_box_overlap_ch); an axis whose product origin * inv is not finite (zero or
     // denormal direction component) gets NaN, which the interval test ignores: that axis then constrains nothing
     f3 finv = inv, noi = mk3(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
     if (!(__builtin_fabsf(noi.x) < __builtin_inff())) { finv.x = 0.0f; noi.x = __builtin_nanf(""); }
     if (!(__builtin_fabsf(noi.y) < __builtin_inff())) { finv.y = 0.0f; noi.y = __builtin_nanf(""); }
     if (!(__builtin_fabsf(noi.z) < __builtin_inff())) { finv.z = 0.0f; noi.z = __builtin_nanf(""); }
+    const v2f_ sx = {-__builtin_fabsf(finv.x), __builtin_fabsf(finv.x)}, sy = {-__builtin_fabsf(finv.y), __builtin_fabsf(finv.y)},
+               sz = {-__builtin_fabsf(finv.z), __builtin_fabsf(finv.z)};  // see pair_box_overlap_ch
     SiftProbe probe;
     const cv4p cnodes = sc.c_nodes();
     const cv4p cpairs = sc.c_pairs();
@@ -667,7 +669,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                 // registers; the answer competes with the dense groups' by the same (distance, slot) key.
                 const cv4p rec = cpairs + kPairQuads * leaf_first;
                 const v4f bx = rec[6], bz = rec[7];
-                const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
+                const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap_ch(bx.xy, bx.zw, bz.xy, finv, noi, sx, sy, sz, t_min, upper);
                 const bool pass = box_met && !(HARVEST && lights_only && __float_as_uint(bz.z) == 0u);
                 if (pass) {
                     const v4f q4 = rec[4], q5 = rec[5];
@@ -698,8 +700,8 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             const char* const boxes = (const char*)cpairs + 6 * 16;
             for (uint32_t at = (leaf_first + k) * 128u; at < at_end; at += 128u) {
                 const cv4p box = (cv4p)(boxes + at);
-                const v4f bx = box[0], bz = box[1];  // (lo.x, hi.x, lo.y, hi.y), (lo.z, hi.z, lane mask in two words: see kPairLitMask)
-                const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap(bx.xy, bx.zw, bz.xy, finv, noi, t_min, upper);
+                const v4f bx = box[0], bz = box[1];  // (h.x, c.x, h.y, c.y), (h.z, c.z, lane mask in two words: see kPairLitMask)
+                const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap_ch(bx.xy, bx.zw, bz.xy, finv, noi, sx, sy, sz, t_min, upper);
                 unsigned long long bal = RRT_BALLOT(box_met);
                 if (HARVEST) bal &= whole_query_lanes | (((unsigned long long)__float_as_uint(bz.w) << 32) | (unsigned long long)__float_as_uint(bz.z));
                 const bool pass = __builtin_amdgcn_inverse_ballot_w64(bal);
