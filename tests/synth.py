@@ -161,6 +161,29 @@ def lone_light_desc(width=48, height=40, samples=16):
     }
 
 
+def floor_and_sphere_light_desc(width=48, height=40, samples=16):
+    """A Lambert floor of two triangles and ONE emissive sphere above it, stretched upwards out of the box the reference gives it
+    (shape.rs:129-139): three shapes in a single leaf whose only sphere is the light.  The sifting query tests such a sphere with
+    the rays' own lanes, and the harvesting kernel takes the light's density from that very test."""
+    floor_v = np.array([[-3.0, 0.0, -3.0], [3.0, 0.0, -3.0], [3.0, 0.0, 3.0], [-3.0, 0.0, 3.0]])
+    floor_t = np.array([[0, 2, 1], [0, 3, 2]], dtype=np.int32)
+    ident = ([0.0, 0.0, 0.0], [0.0, 0.0, 0.0], [1.0, 1.0, 1.0])
+    return {
+        "logistics": {"resolution_x": width, "resolution_y": height, "samples": samples, "use_importance_sampling": True},
+        "camera": {"position": [0.0, 2.5, 6.0], "look_at": [0.0, 0.8, 0.0], "up": [0.0, 1.0, 0.0], "fov": 45.0,
+                   "aspect_ratio": width / height, "aperture": 0.0, "focus_distance": 1.0},
+        "textures": [{"type": sceneio.TEX_CONSTANT, "color": [0.7, 0.6, 0.5]}, {"type": sceneio.TEX_CONSTANT, "color": [5.0, 4.0, 3.0]}],
+        "materials": [{"type": sceneio.MAT_LAMBERT, "albedo": 0, "bump": -1, "param": 0.0},
+                      {"type": sceneio.MAT_DIFFUSE_LIGHT, "albedo": 1, "bump": -1, "param": 0.0}],
+        "shapes": [
+            {"type": "mesh", "object": {"vertices": floor_v, "tex": np.zeros((0, 2)), "vidx": floor_t, "tidx": np.full_like(floor_t, -1)},
+             "cull": False, "material": 0, "transform": ident},
+            {"type": "sphere", "radius": 0.5, "material": 1, "transform": ([0.4, 1.2, 0.0], [0.0, -25.0, 10.0], [1.0, 2.5, 1.0])},
+        ],
+        "aggregate": 1,
+    }
+
+
 def host_scene(desc, aggregate=None):
     """The product's host-side scene for a neutral description (constant textures, meshes and spheres).
     aggregate: "List", "BVH" (built on the host) or "BVH_GPU" (built on the device); default: what the description asks for."""

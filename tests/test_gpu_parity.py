@@ -381,6 +381,33 @@ def test_light_densities_come_from_the_shape_not_from_the_tree(gpu):
         assert st["rays"] == int(st_ref[0])
 
 
+@pytest.mark.parametrize("aggregate,nodes", [(0, 1), (1, 3)])
+def test_a_leaf_whose_only_sphere_is_the_light(gpu, aggregate, nodes):
+    """A Lambert floor (two triangles) under one stretched emissive sphere.  As a List the scene is a single leaf whose only sphere
+    is tested by the rays' own lanes while the harvesting kernel takes the light's density (Sphere::pdf, shape.rs:141-147) from
+    that very test; as a BVH the sphere has a leaf to itself.  Hits, frames and ray counts must be the oracle's in both box-test
+    modes, with the pooled schedule and with one path per lane."""
+    d = dict(synth.floor_and_sphere_light_desc(), aggregate=aggregate)
+    o = orc.OracleScene(d)
+    hs = synth.host_scene(d)
+    assert hs.desc.n_nodes == nodes and hs.desc.n_lights == 1
+    g = rrt.Scene(hs)
+    W, H, spp = 48, 40, 16
+    ro, rd = raygen.ray_batch(o, W, H, n_random=4000, seed=22)
+    p_ref, t_ref = o.intersect(ro, rd)
+    assert (p_ref == 2).sum() > 50 and (p_ref == 0).sum() + (p_ref == 1).sum() > 200, "rays should meet the sphere and the floor"
+    ref, st_ref = o.render(W, H, spp, seed=5)
+    for pooled in (True, False):
+        g.set_pooling(pooled)
+        for mode in (rrt.AABB_TIGHT, rrt.AABB_REFERENCE, rrt.AABB_EXHAUSTIVE):
+            p, t = g.hit(ro, rd, aabb_mode=mode)
+            assert np.array_equal(p, p_ref) and np.array_equal(bits(t), bits(t_ref)), "hits differ (pooled %s, mode %d)" % (pooled, mode)
+            img, st = g.render(seed=5, aabb_mode=mode)
+            same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+            assert same.all(), "%d of %d values differ (pooled %s, mode %d)" % ((~same).sum(), same.size, pooled, mode)
+            assert st["rays"] == int(st_ref[0])
+
+
 def test_scene_file_with_a_device_built_or_clean_tree(gpu):
     """rrt_host_scene_load_as: the asset files rendered with the tree built on the device (bit-identical to the host build) and
     with the clean tree (the oracle's List aggregate; on these scenes also the BVH's frame)."""
