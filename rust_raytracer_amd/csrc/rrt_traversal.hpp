@@ -608,12 +608,13 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
         for (uint32_t i = 0; i < kHarvestLights; ++i) harvest[i] = -1.0f;
     for (;;) {
         if (running) {
-            const v4f n0 = cnodes[4 * cur];
-            const v4f n1 = cnodes[4 * cur + 1];
+            const uint32_t node = HARVEST ? 0u : cur;  // (a harvesting query's tree is its root: the node comes by scalar loads)
+            const v4f n0 = cnodes[4 * node];
+            const v4f n1 = cnodes[4 * node + 1];
             bool inside;
             if (sc.is_list) inside = true;
             else if (AABB_MODE == RRT_AABB_TIGHT) {
-                const v4f b0 = cnodes[4 * cur + 2], b1 = cnodes[4 * cur + 3];
+                const v4f b0 = cnodes[4 * node + 2], b1 = cnodes[4 * node + 3];
                 inside = box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
             } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
             const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
