@@ -899,6 +899,17 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                 if (partner[i] == 0xffffffffu) emit(tri[i], tri[i], false);
                 else if (partner[i] > i) emit(tri[i], tri[partner[i]], true);
             }
+            if (shallow && (((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair - (direct ? 1u : 0u)) & 1u) != 0u) {
+                // the sifting loop takes two records per turn: an odd leaf gets a record whose box no ray meets (its half-widths are
+                // negative); it is never listed, so its primitive fields are never read
+                const size_t at = pairs.size();
+                pairs.resize(at + 4 * kPairQuads, 0.0f);
+                pairs[at + 18] = pairs[at + 19] = put_u(RRT_KIND_NONE << 30);
+                for (int c = 0; c < 3; ++c) {  // written as (lo, hi) = (1, -1): becomes half-width -1, centre 0 below
+                    pairs[at + 24 + 2 * c] = 1.0f;
+                    pairs[at + 24 + 2 * c + 1] = -1.0f;
+                }
+            }
             n.a = first_pair;
             n.b = RRT_LEAF_FLAG | ((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair);
             if (direct) n.b |= kLeafDirect;  // (a shallow tree holds at most 2^25 pair records: the bit is free)
@@ -912,7 +923,7 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
                     const float lo = b[2 * c], hi = b[2 * c + 1];
                     const float mid = 0.5f * lo + 0.5f * hi;
                     const float half = std::nextafter(std::fmax(hi - mid, mid - lo), std::numeric_limits<float>::infinity());
-                    b[2 * c] = half;
+                    b[2 * c] = lo > hi ? -1.0f : half;  // (a padding record's box: see kPadBoxBits)
                     b[2 * c + 1] = mid;
                 }
             }

@@ -493,6 +493,9 @@ constexpr uint32_t kLeafDirect = 0x40000000u;  // in a shallow tree's leaf node,
 // only collect light distances stay), zero when it does not (they are struck) - two words, so that the scalar unit takes them as one
 // 64-bit operand.
 constexpr uint32_t kPairLitMask = 0xffffffffu;
+// The half-width of a padding record's box (the host evens out a shallow leaf's number of sifted records with one): negative, so the
+// near distance lies beyond the far one on every axis the ray moves along, and no ray meets it.
+constexpr uint32_t kPadBoxBits = 0xbf800000u;  // -1.0f
 constexpr uint32_t kSiftCap = 512;  // items the candidate list holds (the CAP template argument below; a caller short of LDS passes less)
 constexpr uint32_t kHarvestLights = 3;
 constexpr uint32_t sift_bytes(uint32_t cap) { return 64 * 8 + cap * 4; }
@@ -699,12 +702,13 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             static_assert(kPairQuads * 16u == 128u, "a list entry's pair field is the record's byte offset");
             const uint32_t at_end = (leaf_first + leaf_pairs) * 128u;
             const char* const boxes = (const char*)cpairs + 6 * 16;
-            for (uint32_t at = (leaf_first + k) * 128u; at < at_end; at += 128u) {
-                const cv4p box = (cv4p)(boxes + at);
-                const v4f bx = box[0], bz = box[1];  // (h.x, c.x, h.y, c.y), (h.z, c.z, lane mask in two words: see kPairLitMask)
+            // Two pairs per turn (the host pads a leaf's records to an even number with a box no ray meets): the two boxes are loaded
+            // together and waited for once, and the turn's scalar work - the step, the room check - is shared by both.
+            auto list_pair = [&](uint32_t at, v4f bx, v4f bz) {
                 const bool box_met = AABB_MODE == kAabbExhaustive ? upper != -__builtin_inff() : pair_box_overlap_ch(bx.xy, bx.zw, bz.xy, finv, noi, sx, sy, sz, t_min, upper);
                 unsigned long long bal = RRT_BALLOT(box_met);
                 if (HARVEST) bal &= whole_query_lanes | (((unsigned long long)__float_as_uint(bz.w) << 32) | (unsigned long long)__float_as_uint(bz.z));
+                if (AABB_MODE == kAabbExhaustive) bal &= RRT_BALLOT(__float_as_uint(bx.x) != kPadBoxBits);  // (this mode has no box test to keep the padding out)
                 const bool pass = __builtin_amdgcn_inverse_ballot_w64(bal);
                 if (pass) {  // (the prefix count starts from the list's length: the place in the list in two instructions)
                     const uint32_t place = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, n_items));
@@ -713,7 +717,19 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                 }
                 n_items += (uint32_t)__popcll(bal);
                 probe.pair_tested();
-                if (n_items > CAP - 64u) {
+            };
+            // (only in the variants without textures, bump maps and media: the others are several times the instruction cache, and
+            // a second copy of the loop's body costs them more than the shared scalar work saves - Example_Spec 3 % slower)
+            constexpr bool kTwoPerTurn = (FEAT & (F_TEX | F_BUMP | F_MEDIUM)) == 0u;
+            for (uint32_t at = (leaf_first + k) * 128u; at < at_end; at += kTwoPerTurn ? 256u : 128u) {
+                const cv4p box = (cv4p)(boxes + at);
+                const v4f bx0 = box[0], bz0 = box[1];  // (h.x, c.x, h.y, c.y), (h.z, c.z, lane mask in two words: see kPairLitMask)
+                list_pair(at, bx0, bz0);
+                if (kTwoPerTurn) {
+                    const v4f bx1 = box[kPairQuads], bz1 = box[kPairQuads + 1];
+                    list_pair(at + 128u, bx1, bz1);
+                }
+                if (n_items > CAP - 128u) {
                     probe.flushed(n_items);
                     sift_flush<FEAT, HARVEST, CAP>(sc, r, t_min, t_max, key, depth, items, n_items, best);
                     probe.dense_done();
