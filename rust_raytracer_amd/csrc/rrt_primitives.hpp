@@ -233,11 +233,6 @@ RRT_DEV float min_as_is(float a, float b) {
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
-RRT_DEV float max_as_is(float a, float b) {
-    float r;
-    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
 RRT_DEV bool pair_box_overlap(v2f_ x, v2f_ y, v2f_ z, f3 inv, f3 noi, float t_min, float t_max) {
     const v2f_ tx = __builtin_elementwise_fma(x, v2f_{inv.x, inv.x}, v2f_{noi.x, noi.x});
     const v2f_ ty = __builtin_elementwise_fma(y, v2f_{inv.y, inv.y}, v2f_{noi.y, noi.y});
@@ -252,21 +247,15 @@ RRT_DEV bool pair_box_overlap(v2f_ x, v2f_ y, v2f_ z, f3 inv, f3 noi, float t_mi
 // the far distance of the axis from it: h * (-|inv|, +|inv|) + (tc, tc) - no minimum and maximum per axis: 11 vector instructions
 // instead of 14.  `s*` = (-|inv|, +|inv|) per axis.  The half-widths are rounded up on the host, so the stored box contains the
 // padded one; the arithmetic's rounding is, as above, a few 1e-7 of the coordinates against a padding of 1e-5 of the extent.
-// (The packed instruction takes the half-width from the low word of the scalar pair for both halves and the centre distance from
-// the low word of its register pair: op_sel_hi 0 for those two operands.)
+// (The compiler gives the packed instruction the half-width and the centre distance once each: op_sel_hi 0 makes both halves read
+// the low word, no copies are made.)
 RRT_DEV v2f_ near_far(v2f_ hc, v2f_ s, float inv, float noi) {
-#pragma clang diagnostic push
-#pragma clang diagnostic ignored "-Wuninitialized"
-    v2f_ tc;  // (the high word is never read: the instruction below takes the low word twice)
-    tc.x = __builtin_fmaf(hc.y, inv, noi);
-#pragma clang diagnostic pop
-    v2f_ nf;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel_hi:[0,1,0]" : "=v"(nf) : "s"(hc), "v"(s), "v"(tc));
-    return nf;
+    const float tc = __builtin_fmaf(hc.y, inv, noi);
+    return __builtin_elementwise_fma(v2f_{hc.x, hc.x}, s, v2f_{tc, tc});
 }
 RRT_DEV bool pair_box_overlap_ch(v2f_ hcx, v2f_ hcy, v2f_ hcz, f3 inv, f3 noi, v2f_ sx, v2f_ sy, v2f_ sz, float t_min, float t_max) {
     const v2f_ tx = near_far(hcx, sx, inv.x, noi.x), ty = near_far(hcy, sy, inv.y, noi.y), tz = near_far(hcz, sz, inv.z, noi.z);
-    const float t_near = __builtin_fmaxf(__builtin_fmaxf(tx.x, ty.x), max_as_is(tz.x, t_min));
+    const float t_near = __builtin_fmaxf(__builtin_fmaxf(tx.x, ty.x), __builtin_fmaxf(tz.x, t_min));
     const float t_far = __builtin_fminf(__builtin_fminf(tx.y, ty.y), min_as_is(tz.y, t_max));
     return t_near <= t_far;
 }
