@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstdlib>
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
             Hit hit;
             unsigned char* area = (unsigned char*)(lds_stack + kTraceBlock * ta.stack_depth);
             float harvest[kHarvestLights];
-            hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
+            hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST, kSiftCap, true, false>(sc, valid, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
             if (valid) {
                 ++rays;
                 f3 radiance;
@@ -173,9 +174,38 @@ enum : uint32_t { C_FREE = 0, C_TRACE = 1, C_GEN = 2, C_LTRI = 3, C_LCS = 4, kCl
 constexpr uint32_t kPoolMaxDepth = 255, kPoolMaxSamples = 1u << 19;
 constexpr size_t pool_bytes_per_wave(bool harvest) { return sift_bytes(kPoolSiftCap) + (harvest ? kHarvestBytesPerWave : 0u) + (size_t)kPoolFields * kPool * 4; }
 
+// The kernel's argument block as it lies in memory.  The wave's loop runs for the whole launch, and an argument the compiler has
+// in a scalar register at its top stays there to its end - 76 of the 102 scalar registers, were all of them held, so most were
+// parked in lanes of a vector register and fetched back (one vector instruction each) in the middle of the hot steps.  What only the
+// sample-drawing step and the kernel's last lines need (the camera, the frame's and the pass's numbers, the counters) is therefore
+// read from the argument block where it is used, through a pointer the compiler cannot see through.
+struct PoolKernArgs {
+    DScene sc;
+    TraceArgs ta;
+    float* slab;
+    unsigned long long* counters;
+    uint32_t* item_counter;
+};
+typedef const PoolKernArgs RRT_CONST_AS* pool_args_p;
+template <class T>
+RRT_DEV T load_words(const T RRT_CONST_AS* p) {  // a struct of 32-bit words out of the constant address space (scalar loads)
+    static_assert(sizeof(T) % 4 == 0, "whole words");
+    T v;
+    const uint32_t RRT_CONST_AS* q = (const uint32_t RRT_CONST_AS*)p;
+    uint32_t w[sizeof(T) / 4];
+    for (size_t i = 0; i < sizeof(T) / 4; ++i) w[i] = q[i];
+    __builtin_memcpy(&v, w, sizeof(T));
+    return v;
+}
+RRT_DEV pool_args_p pool_args_now() {
+    pool_args_p p = (pool_args_p)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));  // (loads through p stay where they are written: not hoisted out of the loop, not held across it)
+    return p;
+}
+
 template <int AABB_MODE, uint32_t FEAT, bool HARVEST>
-__global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__ counters,
-                                                                        uint32_t* __restrict__ item_counter) {
+__global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene sc, TraceArgs ta, float* __restrict__ slab, unsigned long long* __restrict__,
+                                                                        uint32_t* __restrict__) {
     extern __shared__ uint32_t lds_stack[];
     constexpr bool kPlainRecord = (FEAT & (F_TEX | F_BUMP | F_MEDIUM)) == 0;  // one shading record per slot: see DScene::plain
     const uint32_t lane = threadIdx.x;
@@ -233,34 +263,38 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
 
         if (phase == C_FREE) {
             // ≙ main.rs:150-157, 227-229: the next samples of the wave's item (a new item when this one is used up)
+            const pool_args_p cold = pool_args_now();
             if (next >= item_size) {
+                const TraceArgs t = load_words(&cold->ta);
                 uint32_t item = 0;
-                if (lane == 0) item = atomicAdd(item_counter, 1u);
+                if (lane == 0) item = atomicAdd(cold->item_counter, 1u);
                 item = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
-                if (item >= ta.n_items) {
+                if (item >= t.n_items) {
                     exhausted = true;
                     continue;
                 }
-                const uint32_t chunk = item / ta.n_t8, j = item % ta.n_t8;
-                const uint32_t tile32 = ta.tile_index + (j >> 4) * ta.tile_count;
-                x0 = (tile32 % ta.tiles_x) * 32u + ((j & 3u) << 3);
-                y0 = (tile32 / ta.tiles_x) * 32u + (((j >> 2) & 3u) << 3);
-                s0 = chunk * ta.chunk;
-                item_size = (ta.n_samples - s0 < ta.chunk ? ta.n_samples - s0 : ta.chunk) * 64u;
+                const uint32_t chunk = item / t.n_t8, j = item % t.n_t8;
+                const uint32_t tile32 = t.tile_index + (j >> 4) * t.tile_count;
+                x0 = (tile32 % t.tiles_x) * 32u + ((j & 3u) << 3);
+                y0 = (tile32 / t.tiles_x) * 32u + (((j >> 2) & 3u) << 3);
+                s0 = chunk * t.chunk;
+                item_size = (t.n_samples - s0 < t.chunk ? t.n_samples - s0 : t.chunk) * 64u;
                 next = 0;
             }
             const uint32_t take = n < item_size - next ? n : item_size - next;
             const uint32_t idx = next + lane;
             const uint32_t px = x0 + (idx & 7u), py = y0 + ((idx >> 3) & 7u), smp = s0 + (idx >> 6);
-            const bool valid = lane < take && px < ta.W && py < ta.H;  // pixels beyond the frame's edge use up their samples, no slot
+            const uint32_t W = cold->ta.W, H = cold->ta.H;
+            const bool valid = lane < take && px < W && py < H;  // pixels beyond the frame's edge use up their samples, no slot
             if (valid) {
-                Rng g = rng_seed(ta.seed, py * ta.W + px, ta.first_sample + smp);
-                const Ray r = camera_ray(sc.cam, px, py, ta.W, ta.H, g);
+                const rrt_camera cam = load_words(&cold->sc.cam);
+                Rng g = rng_seed(cold->ta.seed, py * W + px, cold->ta.first_sample + smp);
+                const Ray r = camera_ray(cam, px, py, W, H, g);
                 POOL(P_OX, slot) = __float_as_uint(r.o.x); POOL(P_OY, slot) = __float_as_uint(r.o.y); POOL(P_OZ, slot) = __float_as_uint(r.o.z);
                 POOL(P_DX, slot) = __float_as_uint(r.d.x); POOL(P_DY, slot) = __float_as_uint(r.d.y); POOL(P_DZ, slot) = __float_as_uint(r.d.z);
                 POOL(P_TX, slot) = __float_as_uint(1.0f); POOL(P_TY, slot) = __float_as_uint(1.0f); POOL(P_TZ, slot) = __float_as_uint(1.0f);
                 POOL(P_G0, slot) = g.s0; POOL(P_G1, slot) = g.s1;
-                POOL(P_PIX, slot) = py * ta.W + px;
+                POOL(P_PIX, slot) = py * W + px;
                 POOL(P_META, slot) = C_TRACE | (smp << 13);
                 ++paths;
             }
@@ -288,7 +322,7 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
         if (phase == C_TRACE) {
             // ≙ aggregate.rs:24: the closest hit; then whatever decides which shading code the path needs
             float harvest[kHarvestLights];
-            const Hit hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST, kPoolSiftCap, false>(sc, have, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
+            const Hit hit = closest_hit_sift<AABB_MODE, FEAT, HARVEST, kPoolSiftCap, false, false>(sc, have, r, RRT_T_MIN, RRT_T_MAX, g, depth, stack, kTraceBlock, area, harvest);
             uint32_t cls = C_FREE;
             if (have) {
                 ++rays;
@@ -398,6 +432,7 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
     }
 #undef POOL
     probe.store(lane);
+    unsigned long long* const counters = pool_args_now()->counters;
     if (counters) {
         for (int off = 32; off > 0; off >>= 1) {
             rays += __shfl_down(rays, off);
@@ -682,12 +717,165 @@ extern "C" {
 // only if the reference's test accepts the reference's box AND the ray overlaps this box: a node rejected by the second
 // condition holds nothing the ray can hit, so the closest hit (and every later decision, which depends only on the
 // closest distance so far) is the reference's.  Two float4 per node: (lo, 0), (hi, 0).
-static float box_pad(const rrt_scene_desc* d) {
+// Shallow trees (the sifting query's) get a padding a thousand times wider, and with it the grazing guard (grazes_a_plane in
+// rrt_traversal.hpp): the wider the padding, the closer to a triangle's plane a ray may run before the guard has to take its
+// shortcuts away.  Their boxes are few and large, so the width costs next to nothing there; on a mesh it would swallow the triangles.
+#ifndef RRT_SHALLOW_PAD
+#define RRT_SHALLOW_PAD 1.0e-2f
+#endif
+static bool is_shallow(const rrt_scene_desc* d) { return d->aggregate_kind != RRT_AGGREGATE_BVH_CLEAN && d->n_nodes <= kDeepTreeNodes; }
+// across: the padding of every box face (deep trees), and in shallow trees the padding of a triangle's box ACROSS the triangle's
+// plane; along: shallow trees, the padding of a triangle's box along its plane.  The wide padding goes along the plane only: a wall's
+// box stays a thin slab, which a ray that leaves the wall has left before its span begins.
+struct Pads { float across, along; };
+static Pads box_pads(const rrt_scene_desc* d) {
     float scene_max = 0.0f;
     for (uint32_t i = 0; i < d->n_nodes; ++i)
         for (int c = 0; c < 3; ++c) scene_max = std::fmax(scene_max, std::fmax(std::fabs(d->nodes[i].bmin[c]), std::fabs(d->nodes[i].bmax[c])));
     for (int c = 0; c < 3; ++c) scene_max = std::fmax(scene_max, std::fabs(d->camera.origin[c]));  // ray origins: the camera or a surface
-    return 1.0e-5f * scene_max + 1.0e-30f;
+    if (!is_shallow(d)) return {1.0e-5f * scene_max + 1.0e-30f, 1.0e-5f * scene_max + 1.0e-30f};
+    return {2.0e-5f * scene_max + 1.0e-30f, RRT_SHALLOW_PAD * scene_max + 1.0e-30f};
+}
+
+static void pair_box(const rrt_scene_desc* d, uint32_t first, uint32_t count, Pads pads, float* b);
+
+// The table of the grazing guard (layout and meaning: grazes_a_plane in rrt_traversal.hpp): a sphere around all triangle vertices
+// of the scene (the leaves' triangles and those that bound media), and one scaled normal per distinct plane direction.
+static std::vector<float> guard_table(const rrt_scene_desc* d, Pads pads) {
+    struct Plane { double n[3], scale; };
+    std::vector<Plane> planes;
+    std::vector<const rrt_slot*> tris;
+    for (uint32_t i = 0; i < d->n_slots; ++i)
+        if (RRT_INFO_KIND(d->slots[i].info) == RRT_KIND_TRIANGLE) tris.push_back(&d->slots[i]);
+    for (uint32_t i = 0; i < d->n_boundary_tris; ++i) tris.push_back(&d->boundary_tris[i]);
+    auto put_u = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
+    const float inf = std::numeric_limits<float>::infinity();
+    if (tris.empty()) return {0.0f, 0.0f, 0.0f, 0.0f, inf, inf, inf, put_u(2u), inf, 0.0f, 0.0f, 0.0f, inf, inf, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // nothing to graze
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    bool any = false;
+    // the other primitives' boxes count for the sphere too: rays start on them (the render kernels' reach)
+    std::vector<std::array<double, 3>> corners;
+    for (uint32_t i = 0; i < d->n_slots; ++i) {
+        if (RRT_INFO_KIND(d->slots[i].info) == RRT_KIND_TRIANGLE) continue;
+        float b[8];
+        pair_box(d, i, 1, Pads{0.0f, 0.0f}, b);
+        for (int k = 0; k < 8; ++k) corners.push_back({(double)b[(k & 1) ? 4 : 0], (double)b[(k & 2) ? 5 : 1], (double)b[(k & 4) ? 6 : 2]});
+    }
+    for (const auto& p : corners) {
+        for (int c = 0; c < 3; ++c) {
+            if (!any || p[c] < lo[c]) lo[c] = p[c];
+            if (!any || p[c] > hi[c]) hi[c] = p[c];
+        }
+        any = true;
+    }
+    auto vertices = [](const rrt_slot& t, double v[3][3]) {
+        for (int c = 0; c < 3; ++c) {
+            v[0][c] = t.v0[c];
+            v[1][c] = (double)t.v0[c] + (double)t.e1[c];
+            v[2][c] = (double)t.v0[c] + (double)t.e2[c];
+        }
+    };
+    for (const rrt_slot* t : tris) {
+        double v[3][3];
+        vertices(*t, v);
+        for (int k = 0; k < 3; ++k)
+            for (int c = 0; c < 3; ++c) {
+                if (!any || v[k][c] < lo[c]) lo[c] = v[k][c];
+                if (!any || v[k][c] > hi[c]) hi[c] = v[k][c];
+            }
+        any = true;
+    }
+    float centre[3];
+    for (int c = 0; c < 3; ++c) centre[c] = (float)(0.5 * lo[c] + 0.5 * hi[c]);
+    double far2 = 0.0;
+    for (const rrt_slot* t : tris) {
+        double v[3][3];
+        vertices(*t, v);
+        for (int k = 0; k < 3; ++k) {
+            double s = 0.0;
+            for (int c = 0; c < 3; ++c) s += (v[k][c] - centre[c]) * (v[k][c] - centre[c]);
+            far2 = std::fmax(far2, s);
+        }
+    }
+    for (const auto& p : corners) {
+        double s = 0.0;
+        for (int c = 0; c < 3; ++c) s += (p[c] - centre[c]) * (p[c] - centre[c]);
+        far2 = std::fmax(far2, s);
+    }
+    const float rho = std::nextafter((float)std::sqrt(far2), inf);
+    constexpr double kUnitRoundoff = 5.9604644775390625e-08;  // 2^-24
+    double longest_reach = 3.0e38;
+    // directions whose unit normals differ by less (sine of the angle) share an entry; the 1.05 below covers it: no guarded cone
+    // is narrower than 27 u * rho / (0.95 pads.along), and the tolerance is a twenty-fifth of that at most
+    const double merge = std::fmin(2.0e-6, 0.04 * 27.0 * kUnitRoundoff * (double)rho / (0.95 * (double)pads.along));
+    const size_t window = tris.size() <= 4096 ? tris.size() : 64;  // (a huge List over a mesh: only recent entries are looked through)
+    for (const rrt_slot* t : tris) {
+        const double e1[3] = {t->e1[0], t->e1[1], t->e1[2]}, e2[3] = {t->e2[0], t->e2[1], t->e2[2]};
+        double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+        const double a2 = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+        const double l1 = std::sqrt(e1[0] * e1[0] + e1[1] * e1[1] + e1[2] * e1[2]), l2 = std::sqrt(e2[0] * e2[0] + e2[1] * e2[1] + e2[2] * e2[2]);
+        double scale = 0.0;  // a triangle without area: an entry of zero length, which every ray "grazes" (no shortcuts in such a scene)
+        if (a2 > 0.0 && std::isfinite(a2) && std::isfinite(l1 * l2)) {
+            for (int c = 0; c < 3; ++c) n[c] /= a2;
+            // C = (1 + 2 r) (14 + 6 L / reach) + 7 + 6 (1 + L / reach), with L / reach <= L / rho (every reach is at least rho) and <= 2
+            const double ratio = std::fmax(l1 / l2, l2 / l1), rel = std::fmin(std::fmax(l1, l2) / (double)rho, 2.0);
+            scale = (a2 / (l1 * l2)) / ((1.0 + 2.0 * ratio) * (14.0 + 6.0 * rel) + 13.0 + 6.0 * rel);
+            longest_reach = std::fmin(longest_reach, 0.95 * (double)pads.across * (a2 / (l1 * l2)) / ((13.0 + 6.0 * rel) * 1.05 * kUnitRoundoff));
+            // |det| <= |d| |e1| |e2| must stay below the reference's threshold (f32::EPSILON, shape.rs:346-352) for directions whose
+            // squared length is not a normal float (|d| < 1.1e-19): the guard's arithmetic loses its precision there
+            if (!(l1 * l2 < 1.0e12)) longest_reach = 0.0;
+        } else {
+            n[0] = n[1] = n[2] = 0.0;
+            longest_reach = 0.0;
+        }
+        bool merged = false;
+        for (size_t j = planes.size() > window ? planes.size() - window : 0; j < planes.size() && !merged; ++j) {
+            Plane& q = planes[j];
+            const double x[3] = {n[1] * q.n[2] - n[2] * q.n[1], n[2] * q.n[0] - n[0] * q.n[2], n[0] * q.n[1] - n[1] * q.n[0]};
+            const bool both_flat = scale == 0.0 && q.scale == 0.0;
+            if (both_flat || (scale != 0.0 && q.scale != 0.0 && std::sqrt(x[0] * x[0] + x[1] * x[1] + x[2] * x[2]) <= merge)) {
+                q.scale = std::fmin(q.scale, scale);
+                merged = true;
+            }
+        }
+        if (!merged) planes.push_back({{n[0], n[1], n[2]}, scale});
+    }
+    const double unit = 0.95 * (double)pads.along / (1.05 * kUnitRoundoff);
+    float axis[3] = {inf, inf, inf};
+    std::vector<float> general;
+    for (const Plane& q : planes) {
+        int along = -1;  // perpendicular to an axis (to within the merging tolerance): that axis' entry
+        for (int c = 0; c < 3 && q.scale != 0.0; ++c)
+            if (std::sqrt(q.n[(c + 1) % 3] * q.n[(c + 1) % 3] + q.n[(c + 2) % 3] * q.n[(c + 2) % 3]) <= merge) along = c;
+        if (along >= 0) {
+            axis[along] = std::fmin(axis[along], (float)(q.scale * unit));
+            continue;
+        }
+        for (int c = 0; c < 3; ++c) {
+            const double g = q.n[c] * q.scale * unit;
+            general.push_back((float)(std::fabs(g) < 3.0e38 ? g : 0.0));
+        }
+        general.push_back(0.0f);
+    }
+    while (general.size() < 8 || (general.size() / 4) % 2 != 0) {  // (the device takes two per turn, and the first two without asking)
+        const float inert[4] = {inf, 0.0f, 0.0f, 0.0f};  // d . G is infinite, or not a number: no ray is close to it
+        general.insert(general.end(), inert, inert + 4);
+    }
+    // the render kernels' rays start at the camera (camera.rs:54-56: within the lens) or on a primitive
+    double cam2 = 0.0;
+    for (int c = 0; c < 3; ++c) cam2 += ((double)d->camera.origin[c] - centre[c]) * ((double)d->camera.origin[c] - centre[c]);
+    const double start = std::fmax(std::sqrt(cam2) + 2.0 * std::fabs((double)d->camera.lens_radius), (double)rho);
+    const double render_reach = 1.001 * (start + (double)rho);
+    const float render_reach2 = render_reach <= longest_reach ? std::nextafter((float)(render_reach * render_reach * 1.0001), inf) : inf;  // inf: every ray "grazes"
+    std::vector<float> out = {centre[0], centre[1], centre[2], rho, axis[0], axis[1], axis[2], put_u((uint32_t)(general.size() / 4)),
+                              (float)longest_reach, render_reach2, 0.0f, 0.0f};
+    for (size_t k = 0; k + 8 <= general.size(); k += 8) {  // two entries side by side: (x, x, y, y), (z, z, -, -)
+        const float* a = &general[k];
+        const float* b = &general[k + 4];
+        const float two[8] = {a[0], b[0], a[1], b[1], a[2], b[2], 0.0f, 0.0f};
+        out.insert(out.end(), two, two + 8);
+    }
+    return out;
 }
 // b = (lo.xyz, -, hi.xyz, -)
 static void grow_point(float* b, const float* p) {
@@ -706,18 +894,35 @@ static void grow_sphere(float* b, const rrt_sphere& sp) {
         grow_point(b, p);
     }
 }
-static void grow_triangle(float* b, const rrt_slot& t) {
+// A triangle's box, padded by `along` in the triangle's plane and by `across` at right angles to it: on axis c that is
+// along * sqrt(1 - n_c^2) + across * |n_c| for the unit normal n.
+static void grow_triangle(float* b, const rrt_slot& t, Pads pads) {
     float v1[3], v2[3];
     for (int c = 0; c < 3; ++c) {
         v1[c] = t.v0[c] + t.e1[c];
         v2[c] = t.v0[c] + t.e2[c];
     }
-    grow_point(b, t.v0);
-    grow_point(b, v1);
-    grow_point(b, v2);
+    float tb[8];
+    for (int c = 0; c < 3; ++c) {
+        tb[c] = std::fmin(t.v0[c], std::fmin(v1[c], v2[c]));
+        tb[4 + c] = std::fmax(t.v0[c], std::fmax(v1[c], v2[c]));
+    }
+    const double e1[3] = {t.e1[0], t.e1[1], t.e1[2]}, e2[3] = {t.e2[0], t.e2[1], t.e2[2]};
+    const double n[3] = {e1[1] * e2[2] - e1[2] * e2[1], e1[2] * e2[0] - e1[0] * e2[2], e1[0] * e2[1] - e1[1] * e2[0]};
+    const double len = std::sqrt(n[0] * n[0] + n[1] * n[1] + n[2] * n[2]);
+    for (int c = 0; c < 3; ++c) {
+        float pad = std::fmax(pads.along, pads.across);  // (a triangle without area has no plane)
+        if (pads.along != pads.across && len > 0.0 && std::isfinite(len)) {
+            const double nc = std::fmin(std::fabs(n[c] / len), 1.0);
+            pad = std::nextafter((float)((double)pads.along * std::sqrt(1.0 - nc * nc) + (double)pads.across * nc), std::numeric_limits<float>::infinity());
+        }
+        const float at[3] = {tb[0 + c] - pad, tb[4 + c] + pad, 0.0f};
+        b[c] = std::fmin(b[c], at[0]);
+        b[4 + c] = std::fmax(b[4 + c], at[1]);
+    }
 }
 // The padded box of `count` consecutive slots starting at `first`.
-static void pair_box(const rrt_scene_desc* d, uint32_t first, uint32_t count, float pad, float* b) {
+static void pair_box(const rrt_scene_desc* d, uint32_t first, uint32_t count, Pads pads, float* b) {
     const float inf = std::numeric_limits<float>::infinity();
     b[0] = b[1] = b[2] = inf;
     b[4] = b[5] = b[6] = -inf;
@@ -725,25 +930,32 @@ static void pair_box(const rrt_scene_desc* d, uint32_t first, uint32_t count, fl
     for (uint32_t k = 0; k < count; ++k) {
         const rrt_slot& sl = d->slots[first + k];
         const uint32_t kind = RRT_INFO_KIND(sl.info);
-        if (kind == RRT_KIND_TRIANGLE) grow_triangle(b, sl);
-        else if (kind == RRT_KIND_SPHERE) grow_sphere(b, d->spheres[sl.aux]);
+        float pb[8] = {inf, inf, inf, 0.0f, -inf, -inf, -inf, 0.0f};
+        bool padded = false;
+        if (kind == RRT_KIND_TRIANGLE) {
+            grow_triangle(pb, sl, pads);
+            padded = true;
+        } else if (kind == RRT_KIND_SPHERE) grow_sphere(pb, d->spheres[sl.aux]);
         else {
             uint32_t mi = sl.aux;  // every distance a medium reports lies between its boundary's two (volume.rs:79-101)
             while (d->media[mi].boundary_kind == RRT_KIND_MEDIUM) mi = d->media[mi].boundary_index;
             const rrt_medium& m = d->media[mi];
-            if (m.boundary_kind == RRT_KIND_SPHERE) grow_sphere(b, d->spheres[m.boundary_index]);
-            else grow_triangle(b, d->boundary_tris[m.boundary_index]);
+            if (m.boundary_kind == RRT_KIND_SPHERE) grow_sphere(pb, d->spheres[m.boundary_index]);
+            else {
+                grow_triangle(pb, d->boundary_tris[m.boundary_index], pads);
+                padded = true;
+            }
         }
-    }
-    for (int c = 0; c < 3; ++c) {
-        b[c] -= pad;
-        b[4 + c] += pad;
+        for (int c = 0; c < 3; ++c) {
+            b[c] = std::fmin(b[c], pb[c] - (padded ? 0.0f : pads.across));
+            b[4 + c] = std::fmax(b[4 + c], pb[4 + c] + (padded ? 0.0f : pads.across));
+        }
     }
 }
 static std::vector<float> tight_boxes(const rrt_scene_desc* d) {
     const uint32_t n = d->n_nodes;
     std::vector<float> tb((size_t)n * 8, 0.0f);
-    const float pad = box_pad(d);
+    const Pads pad = box_pads(d);
     for (uint32_t i = n; i-- > 0;) {  // pre-order layout: children follow their parent
         const rrt_node& nd = d->nodes[i];
         float* b = &tb[(size_t)i * 8];
@@ -791,7 +1003,7 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     {
         std::vector<rrt_node> dn(desc->nodes, desc->nodes + desc->n_nodes);
         std::vector<float> pairs;
-        const float pad = box_pad(desc);
+        const Pads pad = box_pads(desc);
         auto put_u = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
         // Harvesting (see HARVEST in rrt_device.hpp) needs a single leaf and every light to be one of its primitives:
         // a triangle light is the slot with the same vertex data and cull flag, a sphere light the slot of that sphere.
@@ -864,7 +1076,7 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             // spheres and media get records of their own, at the front of the leaf; a leaf with exactly one of them (too few to fill
             // a dense group of the sifting query; with two, Materials.json renders 1.5 % slower) has it tested by the rays' own lanes
             // (closest_hit_sift), and says so in its node
-            const bool shallow = !clean && desc->n_nodes <= kDeepTreeNodes;  // the sifting query's trees
+            const bool shallow = is_shallow(desc);  // the sifting query's trees
             const bool direct = shallow && count - nt == 1u;
             for (uint32_t k = 0; k < count; ++k)
                 if (RRT_INFO_KIND(desc->slots[first + k].info) != RRT_KIND_TRIANGLE) emit(first + k, first + k, false);
@@ -901,10 +1113,10 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             }
             if (shallow && (((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair - (direct ? 1u : 0u)) & 1u) != 0u) {
                 // the sifting loop takes two records per turn: an odd leaf gets a record whose box no ray meets (its half-widths are
-                // negative); it is never listed, so its primitive fields are never read
+                // negative).  A ray the grazing guard has taken the box tests from lists it all the same: its two primitives are
+                // triangles without area (all zeros, slot 0), which the exact test turns down at the determinant
                 const size_t at = pairs.size();
                 pairs.resize(at + 4 * kPairQuads, 0.0f);
-                pairs[at + 18] = pairs[at + 19] = put_u(RRT_KIND_NONE << 30);
                 for (int c = 0; c < 3; ++c) {  // written as (lo, hi) = (1, -1): becomes half-width -1, centre 0 below
                     pairs[at + 24 + 2 * c] = 1.0f;
                     pairs[at + 24 + 2 * c + 1] = -1.0f;
@@ -914,7 +1126,7 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             n.b = RRT_LEAF_FLAG | ((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair);
             if (direct) n.b |= kLeafDirect;  // (a shallow tree holds at most 2^25 pair records: the bit is free)
         }
-        if (!clean && desc->n_nodes <= kDeepTreeNodes) {
+        if (is_shallow(desc)) {
             // the sifting query (shallow trees) reads a pair's box as half-widths and centres: (h.x, c.x, h.y, c.y | h.z, c.z, ...);
             // a half-width is rounded up past the larger of the two distances, so the stored box contains the padded one
             for (size_t r = 0; r + 4 * kPairQuads <= pairs.size(); r += 4 * kPairQuads) {
@@ -1082,7 +1294,7 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             UP(nodes, (const float4*)rec.data(), rec.size() / 4);
         }
         // the sifting traversal of shallow trees packs (pair, lane) into 32 bits
-        if (!clean && desc->n_nodes <= kDeepTreeNodes && pairs.size() / (4 * kPairQuads) >= (1u << 25))  // (pair number x 128, the record's byte offset, stays below 2^32)
+        if (is_shallow(desc) && pairs.size() / (4 * kPairQuads) >= (1u << 25))  // (pair number x 128, the record's byte offset, stays below 2^32)
             return rrt_set_error(RRT_ERR_LIMIT, "a tree of at most 16 nodes (or a List) with 2^25 pair records or more");
         UP(pairs, (const float4*)pairs.data(), pairs.size() / 4);
     }
@@ -1113,6 +1325,11 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
             }
         }
         UP(plain, (const float4*)rec.data(), rec.size() / 4);
+    }
+    {
+        std::vector<float> guards;
+        if (is_shallow(desc)) guards = guard_table(desc, box_pads(desc));
+        UP(guards, (const float4*)guards.data(), guards.size() / 4);
     }
     UP(slots, (const float4*)desc->slots, (size_t)desc->n_slots * 3);
     UP(tri_shade, (const float4*)desc->tri_shade, (size_t)desc->n_slots * 4);

@@ -43,6 +43,8 @@ struct DScene {
     const rrt_texture* textures;
     const uint8_t* texels;
     const rrt_light* lights;
+    const float4* guards;     // shallow trees: the grazing guard's table - a header of two float4, then one scaled plane normal per
+                              // distinct triangle plane of the scene that is not perpendicular to an axis (see grazes_a_plane)
     uint32_t n_nodes, n_slots, n_lights, is_list;
     uint32_t root_link;  // clean trees: where the walk starts (see walk_step)
     rrt_camera cam;
@@ -59,6 +61,7 @@ struct DScene {
     RRT_DEV cmaterial_p c_materials() const { return (cmaterial_p)(const void*)materials; }
     RRT_DEV ctexture_p c_textures() const { return (ctexture_p)(const void*)textures; }
     RRT_DEV clight_p c_lights() const { return (clight_p)(const void*)lights; }
+    RRT_DEV cv4p c_guards() const { return (cv4p)(const void*)guards; }
 };
 
 struct Ray {

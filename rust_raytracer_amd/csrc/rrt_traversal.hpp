@@ -576,7 +576,68 @@ RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max
     __threadfence_block();
 }
 
-template <int AABB_MODE, uint32_t FEAT, bool HARVEST = false, uint32_t CAP = kSiftCap, bool WANT_UV = true>
+// ---- the grazing guard of the box shortcuts -----------------------------------------------------------------------------
+// The padded boxes of the sifting query (pair boxes, and in TIGHT mode the primitive boxes of a shallow tree's nodes) drop a
+// primitive only when the ray's span misses its box.  That equals the reference - which tests every shape of a visited leaf,
+// aggregate.rs:144-165 - as long as every hit Triangle::hit (shape.rs:335-372) can accept lies inside the padded box.  Its
+// rounding lets in plane crossings OUTSIDE the outline, by a distance that grows as 1 / sin(angle between ray and plane).  With
+// u = 2^-24, a the angle between ray and plane, phi the angle between the triangle's two edges at v0, r the ratio of their lengths
+// (>= 1), L the longer one, every operation of the unfused f32 test rounded once:
+//   crossing point, in the plane   <= u / (sin a * sin phi) * (1 + 2 r) * (14 |o - v0| + 6 L)
+//   hit distance, along the ray    <= u / (sin a * sin phi) * (7 |o - v0| + 6 (|o - v0| + L))     =: ds
+// so the reported point o + t d lies within u * C * reach / (sin a * sin phi) of the triangle in its plane, C = (1 + 2 r) (14 + 6 l)
+// + 7 + 6 (1 + l), and within ds * sin a <= (13 + 6 l) u * reach / sin phi of the plane, where `reach` = |o - centre| + rho bounds
+// |o - v0| (a sphere (centre, rho) holds every primitive of the scene) and l = min(L / rho, 2) bounds L / reach.  A triangle's box
+// is padded by `pad_p` along its plane and by `pad_n` across it, so both shortcuts are exact for a ray with
+//   |d . n| * sin phi / C  >=  |d| * reach * u / (0.95 pad_p)      and      reach <= 0.95 pad_n * sin phi / ((13 + 6 l) u)
+// (a twentieth of the padding is left to the box test's own rounding, a few u of the coordinates).  The host stores, per distinct
+// plane direction of the scene's triangles, G = n * min(sin phi / C) * 0.95 pad_p / (1.05 u) - the 1.05 covers directions merged into
+// one entry although they differ in the sixth digit - and the smallest right-hand side of the second condition, over 1.05.  A ray with |d . G| < |d| * reach
+// for ANY entry, or too long a reach, takes no shortcut at all: every box test of its query is made to pass, so it tests what the
+// reference tests.  With the shallow trees' paddings that is about one ray in two thousand per plane direction.  Returns true for
+// such a ray (and for rays with non-finite or vanishing directions).
+// The table: (centre.xyz, rho), (gx, gy, gz, n) - the lengths of the entries along the three axes (infinite: none; most scenes'
+// walls) and the number of general entries, an even number and at least two (made up with entries no ray is close to:
+// (inf, 0, 0); a scene without triangles has only such entries; two entries share two float4: (x, x, y, y), (z, z, -, -)) -, (longest reach, square of the reach of a ray that starts at the camera or on a primitive, -, -), then the general
+// entries.  ANY_ORIGIN = false (the render kernels, whose rays start at the camera or on a primitive) takes that one reach for
+// every ray instead of working out the ray's own; the host has checked it against the longest reach.
+// (A direction too short for its squared length to be a normal float cannot hit a triangle at all: the reference's determinant
+// test turns it down, and the host checks that the scene's triangles are small enough for that argument.)
+RRT_DEV float min3_abs(float m, float a, float b) {  // min(m, |a|, |b|), NaNs dropped
+    float r;
+    asm("v_min3_f32 %0, %1, |%2|, |%3|" : "=v"(r) : "v"(m), "v"(a), "v"(b));
+    return r;
+}
+// d . Ga and d . Gb for two entries stored side by side (Ga.x, Gb.x, Ga.y, Gb.y | Ga.z, Gb.z, -, -): three packed instructions
+RRT_DEV v2f dot_two(f3 d, v4f xy, v4f z) {
+    return __builtin_elementwise_fma(splat2(d.z), z.xy, __builtin_elementwise_fma(splat2(d.y), xy.zw, splat2(d.x) * xy.xy));
+}
+template <int AABB_MODE, bool ANY_ORIGIN>
+RRT_DEV bool grazes_a_plane(const DScene& sc, const Ray& r) {
+    if (AABB_MODE == kAabbExhaustive) return false;  // (that mode has no shortcut to guard)
+#ifdef RRT_NO_GUARD
+    return false;
+#endif
+    // (the header and the first two general entries - there are always two, inert ones if need be - are fetched together)
+    const cv4p g = sc.c_guards();
+    const v4f h0 = g[0], h1 = g[1], h2 = g[2], Gxy = g[3], Gz = g[4];
+    const uint32_t n = __float_as_uint(h1.w);
+    float m = min3_abs(__builtin_fabsf(r.d.x) * h1.x, r.d.y * h1.y, r.d.z * h1.z);
+    const v2f first = dot_two(r.d, Gxy, Gz);
+    m = min3_abs(m, first.x, first.y);
+    for (uint32_t j = 2; j < n; j += 2u) {
+        const v2f more = dot_two(r.d, g[3u + j], g[4u + j]);
+        m = min3_abs(m, more.x, more.y);
+    }
+    const float dd = __builtin_fmaf(r.d.z, r.d.z, __builtin_fmaf(r.d.y, r.d.y, r.d.x * r.d.x));
+    if (!ANY_ORIGIN) return !(m * m > dd * h2.y);
+    const float ox = r.o.x - h0.x, oy = r.o.y - h0.y, oz = r.o.z - h0.z;
+    const float reach = __builtin_amdgcn_sqrtf(__builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox))) + h0.w;
+    const float lim2 = (dd * (reach * reach)) * 1.0001f;  // (the roundings of this function's own arithmetic)
+    return !(m * m > lim2) || !(reach <= h2.x);
+}
+
+template <int AABB_MODE, uint32_t FEAT, bool HARVEST = false, uint32_t CAP = kSiftCap, bool WANT_UV = true, bool ANY_ORIGIN = true>
 RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, uint32_t* stack,
                              uint32_t stride, unsigned char* area, float* harvest = nullptr) {
     // Must be called by all 64 lanes of the wave (the dense phase addresses lanes by number); lanes without a ray pass
@@ -590,13 +651,16 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long* best = (unsigned long long*)area;
     uint32_t* items = (uint32_t*)(area + 64 * 8);
+    // a ray that runs too close to a triangle's plane for the padded boxes to be trusted (see grazes_a_plane) gets NaN on all
+    // three axes below: every pair box is then met, and so is every node's primitive box
+    const bool graze = grazes_a_plane<AABB_MODE, ANY_ORIGIN>(sc, r);
     const f3 inv = mk3(exact_rcp(r.d.x), exact_rcp(r.d.y), exact_rcp(r.d.z));  // = 1.0f / r.d, bit for bit (see exact_rcp)
     // for the pair boxes: centre * finv + noi (see pair_box_overlap_ch); an axis whose product origin * inv is not finite (zero or
     // denormal direction component) gets NaN, which the interval test ignores: that axis then constrains nothing
     f3 finv = inv, noi = mk3(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
-    if (!(__builtin_fabsf(noi.x) < __builtin_inff())) { finv.x = 0.0f; noi.x = __builtin_nanf(""); }
-    if (!(__builtin_fabsf(noi.y) < __builtin_inff())) { finv.y = 0.0f; noi.y = __builtin_nanf(""); }
-    if (!(__builtin_fabsf(noi.z) < __builtin_inff())) { finv.z = 0.0f; noi.z = __builtin_nanf(""); }
+    if (graze || !(__builtin_fabsf(noi.x) < __builtin_inff())) { finv.x = 0.0f; noi.x = __builtin_nanf(""); }
+    if (graze || !(__builtin_fabsf(noi.y) < __builtin_inff())) { finv.y = 0.0f; noi.y = __builtin_nanf(""); }
+    if (graze || !(__builtin_fabsf(noi.z) < __builtin_inff())) { finv.z = 0.0f; noi.z = __builtin_nanf(""); }
     const v2f_ sx = {-__builtin_fabsf(finv.x), __builtin_fabsf(finv.x)}, sy = {-__builtin_fabsf(finv.y), __builtin_fabsf(finv.y)},
                sz = {-__builtin_fabsf(finv.z), __builtin_fabsf(finv.z)};  // see pair_box_overlap_ch
     SiftProbe probe;
@@ -618,7 +682,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             if (sc.is_list) inside = true;
             else if (AABB_MODE == RRT_AABB_TIGHT) {
                 const v4f b0 = cnodes[4 * node + 2], b1 = cnodes[4 * node + 3];
-                inside = box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
+                inside = (graze || box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t)) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
             } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
             const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
             if (inside && !(b & RRT_LEAF_FLAG)) {

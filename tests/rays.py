@@ -68,7 +68,7 @@ def ray_batch(oracle_scene, W, H, n_random=4096, seed=0, max_corners=4000):
     return ro, rd
 
 
-GRAZER_TILTS = (0.0, 1e-7, 1e-6, 1e-5, 1e-4, 1e-3, 1e-2, 0.1, 1.0)
+GRAZER_TILTS = (0.0, 1e-7, 1e-6, 1e-5, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 0.1, 1.0)
 
 
 def triangle_outline_grazers(slots, extent, seed=0, max_triangles=48, per_edge=6, tilts=GRAZER_TILTS):

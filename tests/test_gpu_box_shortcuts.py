@@ -5,7 +5,9 @@ pairs of a leaf by padded pair boxes before the exact tests.  RRT_AABB_EXHAUSTIV
 sends every primitive of a visited leaf through the exact test, so it equals the reference by construction.  The rays here are
 built for the one place where a shortcut could lose a hit: along triangle outlines, at grazing angles, where Moeller-Trumbore's
 own rounding accepts points slightly OUTSIDE the triangle (aggregate.rs:324-401 tests every shape of a leaf, shape.rs:335-372).
-All three modes must return the oracle's answer bit for bit."""
+On shallow trees (the sifting query: at most 16 nodes, Lists included) a ray that runs closer to a triangle's plane than the
+padding covers loses its shortcuts (the grazing guard), so there all three modes must return the oracle's answer bit for bit;
+deep trees have no guard and keep the weaker contract spelled out in the test."""
 import numpy as np
 import pytest
 
@@ -74,19 +76,22 @@ def misses_grown_box(slots, s, o, d, pad):
 
 
 CASES = ["Cornell_Box_With_Sphere.json", "Cornell_Box.json", "Example_Spec.json", "slats", "slats_list", "soup", "terrain"]
-SAFE_ANGLE = 0.01  # rad off the triangle's plane from which the padding covers the exact test's rounding (see the module text)
+
+SAFE_ANGLE = 0.01  # deep trees: rad off the triangle's plane from which the padding (1e-5 of the extent) covers the exact test's rounding
 
 
 @pytest.mark.parametrize("case", CASES)
 def test_rays_along_triangle_outlines_at_grazing_angles(gpu, case):
     """What the three modes return for rays along triangle outlines:
     * EXHAUSTIVE equals the oracle on every ray, whatever the angle;
-    * TIGHT and REFERENCE equal it on every ray that leaves the plane of the triangle it was aimed at by 0.01 rad or more;
-    * closer to the plane the reference's arithmetic reports "hits" on triangles the ray passes BESIDE (the rounding error of
-      u, v grows as 1/angle and outruns any fixed padding); the shortcuts drop exactly those: every ray they answer differently
-      is one that, in float64, does not touch the reported triangle's box grown by the padding (in a tree: nearly every
-      one - a dropped artefact can also change what the reference's walk prunes afterwards), and they are few."""
+    * shallow trees: so do TIGHT and REFERENCE, on every ray (padded boxes plus the grazing guard);
+    * deep trees: TIGHT and REFERENCE equal it on every ray that leaves the plane of the triangle it was aimed at by 0.01 rad
+      or more; closer to the plane the reference's arithmetic reports "hits" on triangles the ray passes BESIDE (the rounding
+      error of u, v grows as 1/angle and outruns any fixed padding) and TIGHT's node boxes drop exactly those: every ray it
+      answers differently is one that, in float64, does not touch the reported triangle's box grown by the padding (nearly
+      every one - a dropped artefact can also change what the reference's walk prunes afterwards), and they are few."""
     o, g = scene_pair(case)
+    deep = g.host.desc.n_nodes > 16  # the cooperative-leaf walk, whose TIGHT mode has no grazing guard
     slots = g.host.slots()
     bb = o.shape_bboxes()
     extent = float(np.abs(bb[np.isfinite(bb).all(axis=1)]).max())
@@ -101,8 +106,8 @@ def test_rays_along_triangle_outlines_at_grazing_angles(gpu, case):
         for mode in MODES:
             p, t = g.hit(ro, rd, t_min=t_min, aabb_mode=mode)
             bad = (p != p_ref) | (bits(t) != bits(t_ref))
-            if mode == rrt.AABB_EXHAUSTIVE:
-                assert not bad.any(), "exhaustive mode, t_min %g: %d of %d rays differ from the oracle" % (t_min, bad.sum(), len(ro))
+            if mode == rrt.AABB_EXHAUSTIVE or not deep:
+                assert not bad.any(), "mode %d, t_min %g: %d of %d rays differ from the oracle" % (mode, t_min, bad.sum(), len(ro))
                 continue
             steep = angle >= SAFE_ANGLE
             assert not (bad & steep).any(), "mode %d, t_min %g: %d rays at %g rad or more off the plane differ from the oracle" % (
@@ -115,10 +120,7 @@ def test_rays_along_triangle_outlines_at_grazing_angles(gpu, case):
             s = slot_of_prim[p_ref[i]]
             assert ((slots["info"][s] >> 30) == 0).all()
             beside = misses_grown_box(slots, s, ro[i], rd[i], 0.99 * pad)
-            if g.host.desc.n_nodes <= 3:
-                assert beside.all()
-            else:  # in a tree, a dropped rounding artefact can also change which subtrees the reference's walk prunes afterwards
-                assert beside.sum() * 4 >= len(i) * 3
+            assert beside.sum() * 4 >= len(i) * 3  # (a dropped rounding artefact can also change which subtrees the reference's walk prunes afterwards)
     # the batch must contain what it was built for: hits the rounding of the exact test lets in from outside the triangle
     prim_of_slot = slots["prim"].astype(np.int64)
     aimed_hit = (p_ref >= 0) & (prim_of_slot[which] == p_ref)
