@@ -27,6 +27,22 @@ RRT_DEV float exact_rcp(float x) {
 #endif
 }
 
+// The same for the three components of a direction, with ONE test and one rarely taken branch for the wave instead of three
+// (the fast path's scalar instructions - compare, mask juggling, branch - cost issue slots like vector ones).
+RRT_DEV f3 exact_rcp3(f3 x) {
+    const float rx = __builtin_amdgcn_rcpf(x.x), ry = __builtin_amdgcn_rcpf(x.y), rz = __builtin_amdgcn_rcpf(x.z);
+    const float ex = __builtin_fmaf(-x.x, rx, 1.0f), ey = __builtin_fmaf(-x.y, ry, 1.0f), ez = __builtin_fmaf(-x.z, rz, 1.0f);
+    f3 r = mk3(__builtin_fmaf(ex, rx, rx), __builtin_fmaf(ey, ry, ry), __builtin_fmaf(ez, rz, rz));
+    // max3 drops NaNs, so a NaN residual (x zero or not finite) must be caught by its own comparison: !(e <= limit)
+    const bool fine = __builtin_fabsf(ex) <= RRT_RCP_RESIDUAL && __builtin_fabsf(ey) <= RRT_RCP_RESIDUAL && __builtin_fabsf(ez) <= RRT_RCP_RESIDUAL;
+    if (__builtin_expect(RRT_BALLOT(!fine) != 0ull, 0)) {
+        if (!(__builtin_fabsf(ex) <= RRT_RCP_RESIDUAL)) r.x = 1.0f / x.x;
+        if (!(__builtin_fabsf(ey) <= RRT_RCP_RESIDUAL)) r.y = 1.0f / x.y;
+        if (!(__builtin_fabsf(ez) <= RRT_RCP_RESIDUAL)) r.z = 1.0f / x.z;
+    }
+    return r;
+}
+
 // ---- primitives ----------------------------------------------------------------------------------------------
 // Triangle::hit (shape.rs:335-372) on a slot holding v0, e1 = v1 - v0, e2 = v2 - v0.
 RRT_DEV bool triangle_hit(f3 v0, f3 e1, f3 e2, bool cull, const Ray& r, float t_min, float t_max, float* t_out) {

@@ -653,8 +653,17 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
     uint32_t* items = (uint32_t*)(area + 64 * 8);
     // a ray that runs too close to a triangle's plane for the padded boxes to be trusted (see grazes_a_plane) gets NaN on all
     // three axes below: every pair box is then met, and so is every node's primitive box
+#ifdef RRT_EXP_GUARD_IGNORED
+    bool graze = grazes_a_plane<AABB_MODE, ANY_ORIGIN>(sc, r);
+    {
+        unsigned long long gm = RRT_BALLOT(graze);
+        asm volatile("" : "+s"(gm));  // computed, kept alive, not used
+        graze = false;
+    }
+#else
     const bool graze = grazes_a_plane<AABB_MODE, ANY_ORIGIN>(sc, r);
-    const f3 inv = mk3(exact_rcp(r.d.x), exact_rcp(r.d.y), exact_rcp(r.d.z));  // = 1.0f / r.d, bit for bit (see exact_rcp)
+#endif
+    const f3 inv = exact_rcp3(r.d);  // = 1.0f / r.d, bit for bit (see exact_rcp)
     // for the pair boxes: centre * finv + noi (see pair_box_overlap_ch); an axis whose product origin * inv is not finite (zero or
     // denormal direction component) gets NaN, which the interval test ignores: that axis then constrains nothing
     f3 finv = inv, noi = mk3(-(r.o.x * inv.x), -(r.o.y * inv.y), -(r.o.z * inv.z));
@@ -680,7 +689,9 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
             const v4f n1 = cnodes[4 * node + 1];
             bool inside;
             if (sc.is_list) inside = true;
-            else if (AABB_MODE == RRT_AABB_TIGHT) {
+            else if (AABB_MODE == RRT_AABB_TIGHT && !HARVEST) {
+                // (a harvesting query's tree is one leaf: a ray that misses the leaf's primitive box misses every pair box in it,
+                // so the test would decide nothing that the sifting loop does not decide anyway)
                 const v4f b0 = cnodes[4 * node + 2], b1 = cnodes[4 * node + 3];
                 inside = (graze || box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t)) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
             } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
