@@ -696,7 +696,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                 inside = (graze || box_overlap(xyz(b0), xyz(b1), r.o, inv, t_min, h.t)) && aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
             } else inside = aabb_reference(xyz(n0), xyz(n1), r.o, inv, t_min, h.t);
             const uint32_t a = __float_as_uint(n0.w), b = __float_as_uint(n1.w);
-            if (inside && !(b & RRT_LEAF_FLAG)) {
+            if (!HARVEST && inside && !(b & RRT_LEAF_FLAG)) {
                 // aggregate.rs:378-392: with dir[axis] < 0 the left child (cur+1) is popped first, otherwise the right one
                 const float dax = b == 0u ? r.d.x : (b == 1u ? r.d.y : r.d.z);
                 const uint32_t left = cur + 1u, right = a;
@@ -717,7 +717,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                 cur = stack[sp * stride];
             }
         }
-        if (RRT_BALLOT(running) != 0ull) continue;
+        if (!HARVEST && RRT_BALLOT(running) != 0ull) continue;  // (a harvesting query's walk is that one node)
         const unsigned long long waiting = RRT_BALLOT(pending);
         if (waiting == 0ull) break;
         best[lane] = (unsigned long long)ord_bits(h.t) << 32;  // position 0: what the owner already holds wins ties
@@ -729,11 +729,17 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
         probe.sift_begins((uint32_t)__popcll(waiting));
         while (todo != 0ull) {
             // the paused lanes are grouped by leaf (one group for the single-leaf trees of the small scenes)
-            const int leader = __ffsll((long long)todo) - 1;
-            const uint32_t leaf_first = (uint32_t)__builtin_amdgcn_readlane((int)first_pair, leader);
-            const uint32_t leaf_word = (uint32_t)__builtin_amdgcn_readlane((int)n_pairs, leader);
+            uint32_t leaf_first, leaf_word;
+            if (HARVEST) {  // one leaf for everybody: its record comes by scalar loads
+                leaf_first = __float_as_uint(cnodes[0].w);
+                leaf_word = __float_as_uint(cnodes[1].w) & ~RRT_LEAF_FLAG;
+            } else {
+                const int leader = __ffsll((long long)todo) - 1;
+                leaf_first = (uint32_t)__builtin_amdgcn_readlane((int)first_pair, leader);
+                leaf_word = (uint32_t)__builtin_amdgcn_readlane((int)n_pairs, leader);
+            }
             const uint32_t leaf_pairs = leaf_word & ~kLeafDirect;
-            const bool mine = pending && first_pair == leaf_first;
+            const bool mine = HARVEST ? pending : pending && first_pair == leaf_first;
             // Lanes that take no part get an upper bound of -infinity, which no box interval reaches: the loop then runs the same
             // arithmetic in every lane, without masking.  HARVEST: a lane whose ray the leaf's box test kept out only collects light
             // distances, so it is struck from the result of every pair without a light's primitive (a scalar mask operation).
@@ -812,6 +818,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                 }
             }
             todo &= ~RRT_BALLOT(mine);
+            if (HARVEST) break;
         }
         probe.flushed(n_items);
         probe.phase_done();
@@ -829,12 +836,13 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
                 h.det = (low & 1u) ? -1.0f : 1.0f;  // only the sign is used (by the hit properties)
             }
             pending = false;
-            if (sp != 0) {
+            if (!HARVEST && sp != 0) {
                 --sp;
                 cur = stack[sp * stride];
                 running = true;
             }
         }
+        if (HARVEST) break;
     }
     probe.store(lane);
     if (WANT_UV && (FEAT & (F_TEX | F_BUMP)) && h.slot >= 0) {
