@@ -187,12 +187,24 @@ typedef struct rrt_scene rrt_scene; /* device-resident scene */
 typedef struct rrt_host_scene rrt_host_scene; /* host-side builder / loader */
 
 enum { RRT_BG_BLACK = 0 /* main.rs:268-270 */, RRT_BG_SKY = 1 /* main.rs:259-267 */ };
-/* Bounding-box test of the traversal.  All three return the same hits and frames; they differ in what is allowed to cull.
+/* Bounding-box test of the traversal: what is allowed to cull.
  *   TIGHT       the reference's test on its own boxes AND the padded boxes the primitives really occupy (nodes), padded pair boxes
- *               before the exact primitive tests (small scenes): the fast one
- *   REFERENCE   nodes by aggregate.rs:471-503 verbatim alone (the padded pair boxes of small scenes still apply)
+ *               before the exact primitive tests (shallow trees): the fast one
+ *   REFERENCE   nodes by aggregate.rs:471-503 verbatim alone (the padded pair boxes of shallow trees still apply)
  *   EXHAUSTIVE  nodes by the reference's test alone and every primitive of a visited leaf through the exact test: no padded box
- *               decides anything, so it is the reference's result by construction - the yardstick for the other two */
+ *               decides anything, so it is the reference's result by construction - the yardstick for the other two
+ * What each promises:
+ *   shallow trees (at most 16 nodes, Lists included - every scene file of the reference): all three return the same hits and
+ *     frames, bit for bit.  A padded box can only drop a "hit" that the rounding of Triangle::hit (shape.rs:335-372) lets in from
+ *     BESIDE a triangle, for a ray that runs almost inside the triangle's plane; such rays are recognised (a test of the ray's
+ *     direction against every plane direction of the scene, with the worst-case rounding bound of the triangle test) and take no
+ *     shortcut at all.  Spheres rely on the padding alone (their test's rounding stays 50 times below it in scenes like the
+ *     reference's; no bound is proven for a sphere a thousand radii away from the ray's origin).
+ *   deep trees (more than 16 nodes): REFERENCE and EXHAUSTIVE are the same thing there (leaves are always tested whole) and
+ *     equal the reference; TIGHT has no such recognition and may drop exactly those rounding artefacts for rays closer than
+ *     about 0.01 rad to a triangle's plane (a few rays in 10 000 of a batch aimed along triangle outlines, none in a frame checked).
+ *   clean trees (RRT_AGGREGATE_BVH_CLEAN): the mode is ignored - their traversal is their own (byte-quantised padded boxes,
+ *     the reference's List semantics, see rrt_host_finalize), with TIGHT's contract for grazing rays. */
 enum { RRT_AABB_TIGHT = 0, RRT_AABB_REFERENCE = 1, RRT_AABB_EXHAUSTIVE = 2 };
 
 typedef struct rrt_render_params {
@@ -323,10 +335,12 @@ int rrt_render_multi(rrt_scene* const* scenes, uint32_t n, uint32_t shard_mode, 
  * serving loops, harnesses that forbid hipMalloc).  No counterpart in the reference.  Same arguments, same results bit for bit;
  * the per-sample radiance staging lives in an area of RRT_NOALLOC_STAGING_BYTES that is part of the library's code object (one
  * copy per GPU, held until the process ends) instead of the scene handle's own buffer, and the call makes no hipMalloc, hipFree,
- * event creation or other allocating call: kernel launches on `stream` only.  A frame whose samples do not all fit is traced in
- * several passes.  Limits: width * height * 12 bytes must not exceed RRT_NOALLOC_STAGING_BYTES (11 184 810 pixels), else
+ * event creation or other allocating call: kernel launches, and a memset of the scene handle's work-item counters, on `stream` only.
+ * A frame whose samples do not all fit is traced in several passes.  Limits: width * height * 12 bytes must not exceed RRT_NOALLOC_STAGING_BYTES (11 184 810 pixels), else
  * RRT_ERR_LIMIT; rrt_scene_set_timing does not cover these renders.  All calls on one GPU share that GPU's area: calls that
- * overlap in time on one GPU (different streams or scene handles) race; calls on one stream, or ordered by events, do not. */
+ * overlap in time on one GPU (different streams or scene handles) race; calls on one stream, or ordered by events, do not.
+ * Like every render entry point it also uses the handle's work-item counters (zeroed on `stream` before each launch): two renders
+ * of ONE handle must be ordered on the device whichever entry point they use, or they skip and duplicate work items. */
 #define RRT_NOALLOC_STAGING_BYTES (128u << 20)
 int rrt_render_device_noalloc(rrt_scene*, const rrt_render_params* params, float* d_rgb_sum, uint64_t* d_counters, void* stream);
 
@@ -341,7 +355,7 @@ int rrt_scene_set_staging_limit(rrt_scene*, uint64_t bytes);
  * Vec on the host heap, aggregate.rs:352). */
 int rrt_scene_set_lds_stack(rrt_scene*, uint32_t entries);
 
-/* Shallow trees (the asset scenes) with constant textures are traced on a pooled schedule - a wave keeps 160 paths in LDS and
+/* Shallow trees (the asset scenes) with constant textures are traced on a pooled schedule - a wave keeps 128 paths in LDS and
  * runs one kind of work at a time over 64 of them - unless this is switched off (enable = 0: one path per lane, all kinds of work
  * in every turn).  Changes speed only, never results.  No counterpart in the reference. */
 int rrt_scene_set_pooling(rrt_scene*, int enable);

@@ -39,9 +39,12 @@ pub const RRT_TEX_NOISE: u32 = 4;
 pub const RRT_TEX_TURBULENCE: u32 = 5;
 pub const RRT_BG_BLACK: u32 = 0; // main.rs:268-270
 pub const RRT_BG_SKY: u32 = 1; // main.rs:259-267 (commented out in the reference)
-pub const RRT_AABB_TIGHT: u32 = 0;
-pub const RRT_AABB_REFERENCE: u32 = 1; // aggregate.rs:471-503 verbatim
-pub const RRT_AABB_EXHAUSTIVE: u32 = 2; // no padded box culls anything
+// Shallow trees (at most 16 nodes, Lists: every scene file of the reference): all three modes return the same hits, bit for bit.
+// Deep trees: REFERENCE = EXHAUSTIVE = the reference; TIGHT may drop a rounding artefact of the triangle test for a ray within
+// about 0.01 rad of a triangle's plane.  Clean trees ignore the mode (see rrt.h).
+pub const RRT_AABB_TIGHT: u32 = 0; // the reference's node test AND padded primitive boxes
+pub const RRT_AABB_REFERENCE: u32 = 1; // nodes by aggregate.rs:471-503 verbatim alone
+pub const RRT_AABB_EXHAUSTIVE: u32 = 2; // no padded box culls anything: the reference by construction
 pub const RRT_RENDER_ACCUMULATE: u32 = 1;
 pub const RRT_AGGREGATE_LIST: c_int = 0; // "Aggregate": "List", scene.rs:610
 pub const RRT_AGGREGATE_BVH: c_int = 1; // aggregate.rs:187-322 on the host

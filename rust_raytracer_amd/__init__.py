@@ -15,6 +15,9 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("RRT_LIB") or os.path.join(_HERE, "librrt_hip.so")
 
 BG_BLACK, BG_SKY = 0, 1
+# Traversal modes (rrt.h, RRT_AABB_*).  Shallow trees (at most 16 nodes, Lists): all three return the same hits, bit for bit.  Deep
+# trees: REFERENCE = EXHAUSTIVE = the reference; TIGHT may drop a rounding artefact of the triangle test for a ray within about
+# 0.01 rad of a triangle's plane.  Clean trees ignore the mode.
 AABB_TIGHT, AABB_REFERENCE, AABB_EXHAUSTIVE = 0, 1, 2
 RENDER_ACCUMULATE = 1
 SHARD_SAMPLES, SHARD_TILES = 0, 1

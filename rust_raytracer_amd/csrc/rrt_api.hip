@@ -139,7 +139,7 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace(DSce
 // Same paths, same arithmetic, same results as k_trace; what differs is who runs when.  In k_trace each lane owns one path
 // and the wave steps query - shade - query in lockstep, so every branch of the shading code (light hit, glass, Lambert towards a
 // triangle light, Lambert cosine lobe, fresh camera ray ...) runs in every turn of the loop for the handful of lanes that need it:
-// 0.455 of the lanes of an average vector instruction do useful work.  Here a wave keeps a POOL of kPool paths in LDS (16 dwords
+// 0.455 of the lanes of an average vector instruction do useful work.  Here a wave keeps a POOL of kPool paths in LDS (15 dwords
 // each), every path tagged with what it waits for, and each turn of the loop picks ONE kind of work that has 64 paths waiting,
 // pulls those 64 into registers, runs that one piece of code at full width and files the paths under what they wait for next:
 //   FREE   a slot without a path            -> draw a sample, make the camera ray                     -> TRACE
@@ -171,7 +171,7 @@ enum : uint32_t { P_OX, P_OY, P_OZ, P_DX, P_DY, P_DZ, P_TX, P_TY, P_TZ, P_G0, P_
 constexpr uint32_t kPoolMaxLights = 64;
 enum : uint32_t { C_FREE = 0, C_TRACE = 1, C_GEN = 2, C_LTRI = 3, C_LCS = 4, kClasses = 5 };
 // P_META: bits 0..2 class, 3 a diffuse bounce's density is pending, 4 the light-or-lobe draw chose a light, 5..12 depth, 13..31 sample
-constexpr uint32_t kPoolMaxDepth = 255, kPoolMaxSamples = 1u << 19;
+constexpr uint32_t kPoolMaxDepth = 255, kPoolMaxSamples = 1u << 19, kPoolMaxSlots = (1u << 25) - 1u;
 constexpr size_t pool_bytes_per_wave(bool harvest) { return sift_bytes(kPoolSiftCap) + (harvest ? kHarvestBytesPerWave : 0u) + (size_t)kPoolFields * kPool * 4; }
 
 // The kernel's argument block as it lies in memory.  The wave's loop runs for the whole launch, and an argument the compiler has
@@ -612,6 +612,7 @@ struct rrt_scene {
     uint32_t n_spheres = 0, n_media = 0, n_btris = 0, n_materials = 0, n_textures = 0;
     int device = 0;
     double upload_seconds = 0.0;  // host wall clock of rrt_scene_create
+    uint64_t desc_hash = 0;       // of the description's arrays and camera (rrt_render_multi compares its handles)
     // optional per-kernel timing: three events per pass (before k_trace, between the kernels, after k_accumulate)
     bool timing = false;
     std::vector<hipEvent_t> events;  // pool
@@ -1385,6 +1386,23 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, s->device));
         s->wave_places = (uint32_t)(cus > 0 ? cus : 256) * 4u * kPoolWaves;
     }
+    {
+        uint64_t h = 1469598103934665603ull;  // FNV-1a over everything a kernel reads
+        auto mix = [&h](const void* p, size_t n) {
+            const unsigned char* b = (const unsigned char*)p;
+            for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+        };
+        mix(desc->nodes, (size_t)desc->n_nodes * sizeof(rrt_node));
+        mix(desc->slots, (size_t)desc->n_slots * sizeof(rrt_slot));
+        mix(desc->spheres, (size_t)desc->n_spheres * sizeof(rrt_sphere));
+        mix(desc->media, (size_t)desc->n_media * sizeof(rrt_medium));
+        mix(desc->materials, (size_t)desc->n_materials * sizeof(rrt_material));
+        mix(desc->textures, (size_t)desc->n_textures * sizeof(rrt_texture));
+        mix(desc->lights, (size_t)desc->n_lights * sizeof(rrt_light));
+        mix(&desc->camera, sizeof desc->camera);
+        mix(&desc->aggregate_kind, sizeof desc->aggregate_kind);
+        s->desc_hash = h;
+    }
     s->upload_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
     *out = owner.release();
     return RRT_OK;
@@ -1666,7 +1684,9 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
         // 90.6 ms on 500 000 triangles at 1024x1024@64.
         // (k_trace, one block per item: 40 960 items, chunks of 16 at least - shorter blocks cost more in ramp-up and drain than they balance)
         const bool exhaustive = p->aabb_mode == RRT_AABB_EXHAUSTIVE && !s->deep;
-        const bool pooled = !exhaustive && s->pooling && !s->deep && ta.max_depth <= kPoolMaxDepth && ta.n_samples <= kPoolMaxSamples && s->d.n_lights <= kPoolMaxLights;
+        // (the pool packs slot + 1 into 25 bits, the depth into 8, the sample into 19, the chosen light into 6)
+        const bool pooled = !exhaustive && s->pooling && !s->deep && ta.max_depth <= kPoolMaxDepth && ta.n_samples <= kPoolMaxSamples &&
+                            s->d.n_lights <= kPoolMaxLights && s->d.n_slots < kPoolMaxSlots;
         const uint64_t want = s->deep ? 655360 : (pooled ? 163840 : 40960);
         const uint32_t least = s->deep ? 1u : (pooled ? 4u : 16u);
         ta.chunk = kChunk;
@@ -1870,6 +1890,13 @@ static int render_multi(rrt_scene* const* scenes, uint32_t n, uint32_t shard_mod
     for (uint32_t i = 0; i < n; ++i)
         for (uint32_t j = 0; j < i; ++j)
             if (scenes[i] == scenes[j]) return rrt_set_error(RRT_ERR_INVALID, "rrt_render_multi: a scene handle appears twice (one render at a time per handle)");
+    // every handle must hold the same scene: the shares of different scenes would make one frame without a word of warning
+    for (uint32_t i = 1; i < n; ++i) {
+        const rrt_scene *a = scenes[0], *b = scenes[i];
+        if (a->res_x != b->res_x || a->res_y != b->res_y || a->samples != b->samples || a->d.n_slots != b->d.n_slots || a->d.n_nodes != b->d.n_nodes ||
+            a->d.n_lights != b->d.n_lights || a->features != b->features || a->clean != b->clean || a->desc_hash != b->desc_hash)
+            return rrt_set_error(RRT_ERR_INVALID, "rrt_render_multi: scene handle " + std::to_string(i) + " does not hold the same scene description as handle 0");
+    }
     const uint32_t W = p->width ? p->width : scenes[0]->res_x, H = p->height ? p->height : scenes[0]->res_y;
     const uint32_t spp = p->samples ? p->samples : scenes[0]->samples;
     if (W == 0 || H == 0) return rrt_set_error(RRT_ERR_INVALID, "rrt_render_multi: zero resolution");
