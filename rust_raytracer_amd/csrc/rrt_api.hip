@@ -722,26 +722,64 @@ extern "C" {
 // only if the reference's test accepts the reference's box AND the ray overlaps this box: a node rejected by the second
 // condition holds nothing the ray can hit, so the closest hit (and every later decision, which depends only on the
 // closest distance so far) is the reference's.  Two float4 per node: (lo, 0), (hi, 0).
-// Shallow trees (the sifting query's) get a padding a thousand times wider, and with it the grazing guard (grazes_a_plane in
-// rrt_traversal.hpp): the wider the padding, the closer to a triangle's plane a ray may run before the guard has to take its
-// shortcuts away.  Their boxes are few and large, so the width costs next to nothing there; on a mesh it would swallow the triangles.
+// Shallow trees (the sifting query's) get a much wider padding along the triangles' planes, and with it the grazing guard
+// (grazes_a_plane in rrt_traversal.hpp): the wider the padding, the closer to a triangle's plane a ray may run before the guard has
+// to take its shortcuts away.  Their boxes are few and large, so the width costs next to nothing there; on a mesh it would swallow
+// the triangles.
 #ifndef RRT_SHALLOW_PAD
-#define RRT_SHALLOW_PAD 1.0e-2f
+#define RRT_SHALLOW_PAD 1.6e-2
 #endif
 static bool is_shallow(const rrt_scene_desc* d) { return d->aggregate_kind != RRT_AGGREGATE_BVH_CLEAN && d->n_nodes <= kDeepTreeNodes; }
 // across: the padding of every box face (deep trees), and in shallow trees the padding of a triangle's box ACROSS the triangle's
 // plane; along: shallow trees, the padding of a triangle's box along its plane.  The wide padding goes along the plane only: a wall's
-// box stays a thin slab, which a ray that leaves the wall has left before its span begins.
+// box stays a thin slab, which a ray that leaves the wall has left before its span begins.  It is a fraction of the radius of the
+// sphere around the scene's triangles (not of the scene's extent: a small mesh on a huge ground sphere keeps boxes of its own size).
 struct Pads { float across, along; };
+// Centre and radius of a sphere around every triangle vertex of the scene (the leaves' triangles and those that bound media);
+// false when the scene has no triangle.
+static bool triangle_sphere(const rrt_scene_desc* d, double centre[3], double* radius) {
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    bool any = false;
+    auto each_vertex = [&](auto&& f) {
+        auto of = [&](const rrt_slot& t) {
+            for (int k = 0; k < 3; ++k) {
+                double v[3];
+                for (int c = 0; c < 3; ++c) v[c] = (double)t.v0[c] + (k == 1 ? (double)t.e1[c] : (k == 2 ? (double)t.e2[c] : 0.0));
+                f(v);
+            }
+        };
+        for (uint32_t i = 0; i < d->n_slots; ++i)
+            if (RRT_INFO_KIND(d->slots[i].info) == RRT_KIND_TRIANGLE) of(d->slots[i]);
+        for (uint32_t i = 0; i < d->n_boundary_tris; ++i) of(d->boundary_tris[i]);
+    };
+    each_vertex([&](const double* v) {
+        for (int c = 0; c < 3; ++c) {
+            if (!any || v[c] < lo[c]) lo[c] = v[c];
+            if (!any || v[c] > hi[c]) hi[c] = v[c];
+        }
+        any = true;
+    });
+    if (!any) return false;
+    for (int c = 0; c < 3; ++c) centre[c] = (double)(float)(0.5 * lo[c] + 0.5 * hi[c]);  // (the device holds it as floats)
+    double far2 = 0.0;
+    each_vertex([&](const double* v) {
+        double s = 0.0;
+        for (int c = 0; c < 3; ++c) s += (v[c] - centre[c]) * (v[c] - centre[c]);
+        far2 = std::fmax(far2, s);
+    });
+    *radius = std::sqrt(far2);
+    return true;
+}
 static Pads box_pads(const rrt_scene_desc* d) {
     float scene_max = 0.0f;
     for (uint32_t i = 0; i < d->n_nodes; ++i)
         for (int c = 0; c < 3; ++c) scene_max = std::fmax(scene_max, std::fmax(std::fabs(d->nodes[i].bmin[c]), std::fabs(d->nodes[i].bmax[c])));
     for (int c = 0; c < 3; ++c) scene_max = std::fmax(scene_max, std::fabs(d->camera.origin[c]));  // ray origins: the camera or a surface
     if (!is_shallow(d)) return {1.0e-5f * scene_max + 1.0e-30f, 1.0e-5f * scene_max + 1.0e-30f};
-    return {2.0e-5f * scene_max + 1.0e-30f, RRT_SHALLOW_PAD * scene_max + 1.0e-30f};
+    double centre[3], radius = 0.0;
+    if (!triangle_sphere(d, centre, &radius)) radius = 0.0;
+    return {2.0e-5f * scene_max + 1.0e-30f, (float)(RRT_SHALLOW_PAD * radius) + 2.0e-5f * scene_max + 1.0e-30f};
 }
-
 static void pair_box(const rrt_scene_desc* d, uint32_t first, uint32_t count, Pads pads, float* b);
 
 // The table of the grazing guard (layout and meaning: grazes_a_plane in rrt_traversal.hpp): a sphere around all triangle vertices
@@ -756,58 +794,25 @@ static std::vector<float> guard_table(const rrt_scene_desc* d, Pads pads) {
     auto put_u = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
     const float inf = std::numeric_limits<float>::infinity();
     if (tris.empty()) return {0.0f, 0.0f, 0.0f, 0.0f, inf, inf, inf, put_u(2u), inf, 0.0f, 0.0f, 0.0f, inf, inf, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // nothing to graze
-    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
-    bool any = false;
-    // the other primitives' boxes count for the sphere too: rays start on them (the render kernels' reach)
-    std::vector<std::array<double, 3>> corners;
+    double centre_d[3], radius = 0.0;
+    triangle_sphere(d, centre_d, &radius);
+    const float centre[3] = {(float)centre_d[0], (float)centre_d[1], (float)centre_d[2]};
+    const float rho = std::nextafter((float)radius, inf);
+    // how far from that sphere's centre a ray of the render kernels can start: at the camera (camera.rs:54-56: within the lens) or
+    // on a primitive
+    double start2 = 0.0;
+    for (int c = 0; c < 3; ++c) start2 += ((double)d->camera.origin[c] - centre_d[c]) * ((double)d->camera.origin[c] - centre_d[c]);
+    double start = std::sqrt(start2) + 2.0 * std::fabs((double)d->camera.lens_radius);
     for (uint32_t i = 0; i < d->n_slots; ++i) {
-        if (RRT_INFO_KIND(d->slots[i].info) == RRT_KIND_TRIANGLE) continue;
         float b[8];
         pair_box(d, i, 1, Pads{0.0f, 0.0f}, b);
-        for (int k = 0; k < 8; ++k) corners.push_back({(double)b[(k & 1) ? 4 : 0], (double)b[(k & 2) ? 5 : 1], (double)b[(k & 4) ? 6 : 2]});
-    }
-    for (const auto& p : corners) {
-        for (int c = 0; c < 3; ++c) {
-            if (!any || p[c] < lo[c]) lo[c] = p[c];
-            if (!any || p[c] > hi[c]) hi[c] = p[c];
-        }
-        any = true;
-    }
-    auto vertices = [](const rrt_slot& t, double v[3][3]) {
-        for (int c = 0; c < 3; ++c) {
-            v[0][c] = t.v0[c];
-            v[1][c] = (double)t.v0[c] + (double)t.e1[c];
-            v[2][c] = (double)t.v0[c] + (double)t.e2[c];
-        }
-    };
-    for (const rrt_slot* t : tris) {
-        double v[3][3];
-        vertices(*t, v);
-        for (int k = 0; k < 3; ++k)
-            for (int c = 0; c < 3; ++c) {
-                if (!any || v[k][c] < lo[c]) lo[c] = v[k][c];
-                if (!any || v[k][c] > hi[c]) hi[c] = v[k][c];
-            }
-        any = true;
-    }
-    float centre[3];
-    for (int c = 0; c < 3; ++c) centre[c] = (float)(0.5 * lo[c] + 0.5 * hi[c]);
-    double far2 = 0.0;
-    for (const rrt_slot* t : tris) {
-        double v[3][3];
-        vertices(*t, v);
-        for (int k = 0; k < 3; ++k) {
-            double s = 0.0;
-            for (int c = 0; c < 3; ++c) s += (v[k][c] - centre[c]) * (v[k][c] - centre[c]);
-            far2 = std::fmax(far2, s);
+        for (int k = 0; k < 8; ++k) {
+            const double p[3] = {(double)b[(k & 1) ? 4 : 0], (double)b[(k & 2) ? 5 : 1], (double)b[(k & 4) ? 6 : 2]};
+            double s2 = 0.0;
+            for (int c = 0; c < 3; ++c) s2 += (p[c] - centre_d[c]) * (p[c] - centre_d[c]);
+            start = std::fmax(start, std::sqrt(s2));
         }
     }
-    for (const auto& p : corners) {
-        double s = 0.0;
-        for (int c = 0; c < 3; ++c) s += (p[c] - centre[c]) * (p[c] - centre[c]);
-        far2 = std::fmax(far2, s);
-    }
-    const float rho = std::nextafter((float)std::sqrt(far2), inf);
     constexpr double kUnitRoundoff = 5.9604644775390625e-08;  // 2^-24
     double longest_reach = 3.0e38;
     // directions whose unit normals differ by less (sine of the angle) share an entry; the 1.05 below covers it: no guarded cone
@@ -866,14 +871,14 @@ static std::vector<float> guard_table(const rrt_scene_desc* d, Pads pads) {
         const float inert[4] = {inf, 0.0f, 0.0f, 0.0f};  // d . G is infinite, or not a number: no ray is close to it
         general.insert(general.end(), inert, inert + 4);
     }
-    // the render kernels' rays start at the camera (camera.rs:54-56: within the lens) or on a primitive
-    double cam2 = 0.0;
-    for (int c = 0; c < 3; ++c) cam2 += ((double)d->camera.origin[c] - centre[c]) * ((double)d->camera.origin[c] - centre[c]);
-    const double start = std::fmax(std::sqrt(cam2) + 2.0 * std::fabs((double)d->camera.lens_radius), (double)rho);
+    // The render kernels take ONE reach for all their rays when that costs little: when the farthest start is within four radii of
+    // the triangles' sphere (the Cornell boxes).  A small mesh in a wide scene (a cube on a ground sphere of a hundred times its
+    // size) would have nearly every ray "graze" with the far ground's reach; there every ray works out its own.
     const double render_reach = 1.001 * (start + (double)rho);
-    const float render_reach2 = render_reach <= longest_reach ? std::nextafter((float)(render_reach * render_reach * 1.0001), inf) : inf;  // inf: every ray "grazes"
+    const bool own_reach = !(render_reach <= 4.0 * (double)rho) || !(render_reach <= longest_reach);
+    const float render_reach2 = std::nextafter((float)(render_reach * render_reach * 1.0001), inf);
     std::vector<float> out = {centre[0], centre[1], centre[2], rho, axis[0], axis[1], axis[2], put_u((uint32_t)(general.size() / 4)),
-                              (float)longest_reach, render_reach2, 0.0f, 0.0f};
+                              (float)longest_reach, render_reach2, put_u(own_reach ? 1u : 0u), 0.0f};
     for (size_t k = 0; k + 8 <= general.size(); k += 8) {  // two entries side by side: (x, x, y, y), (z, z, -, -)
         const float* a = &general[k];
         const float* b = &general[k + 4];

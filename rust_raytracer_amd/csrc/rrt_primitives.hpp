@@ -215,15 +215,18 @@ RRT_DEV bool aabb_reference(f3 bmin, f3 bmax, f3 o, f3 inv, float t_min, float t
     slab(bmin.x, bmax.x, o.x, inv.x, &t0x, &t1x);
     slab(bmin.y, bmax.y, o.y, inv.y, &t0y, &t1y);
     slab(bmin.z, bmax.z, o.z, inv.z, &t0z, &t1z);
+    // (the reference leaves after the first axis that fails; evaluating all three and combining the verdicts gives the same answer
+    // without two branches - in a wave some lane nearly always needs the next axis anyway)
     float lo = t0x > t_min ? t0x : t_min;
     float hi = t1x < t_min ? t1x : t_max;
-    if (hi <= lo) return false;
+    const bool out1 = hi <= lo;
     float lo2 = t0y > lo ? t0y : lo;
     float hi2 = t1y < lo ? t1y : hi;
-    if (hi2 <= lo2) return false;
+    const bool out2 = hi2 <= lo2;
     float lo3 = t0z > lo2 ? t0z : lo2;
     float hi3 = t1z < lo2 ? t1z : hi2;
-    return !(hi3 <= lo3);
+    const bool out3 = hi3 <= lo3;
+    return !(out1 | out2 | out3);
 }
 
 // Does the ray's (t_min, t_max) span overlap the box?  The ordinary three-slab interval test; min/max drop NaNs (0 * inf

@@ -587,7 +587,7 @@ RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max
 //   hit distance, along the ray    <= u / (sin a * sin phi) * (7 |o - v0| + 6 (|o - v0| + L))     =: ds
 // so the reported point o + t d lies within u * C * reach / (sin a * sin phi) of the triangle in its plane, C = (1 + 2 r) (14 + 6 l)
 // + 7 + 6 (1 + l), and within ds * sin a <= (13 + 6 l) u * reach / sin phi of the plane, where `reach` = |o - centre| + rho bounds
-// |o - v0| (a sphere (centre, rho) holds every primitive of the scene) and l = min(L / rho, 2) bounds L / reach.  A triangle's box
+// |o - v0| (a sphere (centre, rho) holds every triangle vertex of the scene) and l = min(L / rho, 2) bounds L / reach.  A triangle's box
 // is padded by `pad_p` along its plane and by `pad_n` across it, so both shortcuts are exact for a ray with
 //   |d . n| * sin phi / C  >=  |d| * reach * u / (0.95 pad_p)      and      reach <= 0.95 pad_n * sin phi / ((13 + 6 l) u)
 // (a twentieth of the padding is left to the box test's own rounding, a few u of the coordinates).  The host stores, per distinct
@@ -596,11 +596,13 @@ RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max
 // for ANY entry, or too long a reach, takes no shortcut at all: every box test of its query is made to pass, so it tests what the
 // reference tests.  With the shallow trees' paddings that is about one ray in two thousand per plane direction.  Returns true for
 // such a ray (and for rays with non-finite or vanishing directions).
-// The table: (centre.xyz, rho), (gx, gy, gz, n) - the lengths of the entries along the three axes (infinite: none; most scenes'
+// The table: (centre.xyz, rho); (gx, gy, gz, n) - the lengths of the entries along the three axes (infinite: none; most scenes'
 // walls) and the number of general entries, an even number and at least two (made up with entries no ray is close to:
-// (inf, 0, 0); a scene without triangles has only such entries; two entries share two float4: (x, x, y, y), (z, z, -, -)) -, (longest reach, square of the reach of a ray that starts at the camera or on a primitive, -, -), then the general
-// entries.  ANY_ORIGIN = false (the render kernels, whose rays start at the camera or on a primitive) takes that one reach for
-// every ray instead of working out the ray's own; the host has checked it against the longest reach.
+// (inf, 0, 0); a scene without triangles has only such entries); (longest reach, square of the reach of a ray that starts at the
+// camera or on a primitive, flag, -); then the general entries, two to two float4: (x, x, y, y), (z, z, -, -).
+// ANY_ORIGIN = false (the render kernels, whose rays start at the camera or on a primitive) takes that one reach for every ray
+// instead of working out the ray's own, unless the flag is set: the host sets it when the one reach is too long to be useful (a
+// small mesh in a wide scene) or longer than the longest reach.
 // (A direction too short for its squared length to be a normal float cannot hit a triangle at all: the reference's determinant
 // test turns it down, and the host checks that the scene's triangles are small enough for that argument.)
 RRT_DEV float min3_abs(float m, float a, float b) {  // min(m, |a|, |b|), NaNs dropped
@@ -630,7 +632,7 @@ RRT_DEV bool grazes_a_plane(const DScene& sc, const Ray& r) {
         m = min3_abs(m, more.x, more.y);
     }
     const float dd = __builtin_fmaf(r.d.z, r.d.z, __builtin_fmaf(r.d.y, r.d.y, r.d.x * r.d.x));
-    if (!ANY_ORIGIN) return !(m * m > dd * h2.y);
+    if (!ANY_ORIGIN && __float_as_uint(h2.z) == 0u) return !(m * m > dd * h2.y);
     const float ox = r.o.x - h0.x, oy = r.o.y - h0.y, oz = r.o.z - h0.z;
     const float reach = __builtin_amdgcn_sqrtf(__builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox))) + h0.w;
     const float lim2 = (dd * (reach * reach)) * 1.0001f;  // (the roundings of this function's own arithmetic)
