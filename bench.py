@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
 """Headline benchmark: Mrays/s on the Cornell box with the glass sphere, 1024x1024 @ 1024 spp per GPU.
 
-    python bench.py --gpus N --steps K --warmup W [--config headline|c5] [--shard samples|tiles]
+    python bench.py --gpus N --steps K --warmup W [--config headline|c4|c5] [--shard samples|tiles]
 
 A step is one full render of the frame (1024*1024*1024 camera samples, each traced to termination) with the scene already
 resident in HBM, plus the one collective and the 8-bit resolve.  With N > 1 (launched by torch.distributed.run, one rank per GPU)
 every rank renders its own 1024-sample range of the per-pixel random streams (first_sample = rank * 1024) and the radiance sums
 are combined with ONE RCCL reduce per step, so N GPUs deliver an N*1024-spp frame: weak scaling, and that is `value`.  For N > 1
-the line also carries `strong`: the SAME 1024-spp frame divided over the N GPUs (sample ranges, and interleaved 32x32 tiles),
-timed for the same number of steps after the weak ones.
+the line also carries `strong`: the SAME frame divided over the N GPUs (sample ranges, and interleaved 32x32 tiles), timed for
+the same number of steps after the weak ones, each with `efficiency_vs_1gpu` = (rank 0 rendering the whole frame alone) /
+(N x the divided frame's time), both measured in this run.
+--config c4: assets/Globe.json at 3840x2160 @ 2048 spp (sky background); --config c5: a 10 M-triangle mesh at 3840x2160 @ 16 spp.
 
-Rank 0 prints one JSON line.  `roofline` describes the dominant kernel (the path tracer).  Its launch durations are measured live
-with HIP events that the library records around every launch on the render stream.  The kernel keeps all path state on chip, so
-what bounds it is vector-ALU issue, not HBM: `bound` says so, `achieved`/`peak` are vector wave-instructions per second (the
-instruction count per ray and the lane utilisation come from the committed PMC passes of this same command,
-profiles/pmc_counters.json; the duration is live), and `nominal_hbm_*` keep the figure a queue-based wavefront tracer would be
-priced at (192 B per path segment against 8 TB/s), with `traffic` the HBM bytes the kernel really moves per launch.
+Rank 0 prints one JSON line.  `roofline` describes the dominant kernel (the path tracer): `achieved` = the workload model's bytes
+per ray (192 B per path segment for a scene that stays in cache: what a tracer with ray queues in HBM moves) x the rays of a launch
+/ the launch's duration, measured live with HIP events that the library records around every launch on the render stream;
+`peak` 8 TB/s.  The headline kernel keeps all path state on chip, so it moves a fraction of those bytes (`traffic`, from PMC
+passes) and what really bounds it is vector-ALU issue: `roofline.valu` holds that accounting (instructions per ray, lane
+utilisation, busy fraction, from the committed PMC passes of this same command, profiles/pmc_counters.json).  Those counters
+belong to one build of the kernels: the file records a hash of the kernel sources, and when it does not match the sources this
+run loaded, `traffic` is null, `valu` is left out and `counters_stale` says why.
 `cpu_baseline` times the CPU oracle (a port of the reference's algorithm) on a bounded sample of the same frame on this host's
 cores - all of them (at most 16) and the reference's default of two threads (main.rs:66-72); it is never part of the product path.
 """
@@ -61,12 +65,33 @@ def cpu_baseline(spp, threads):
             "seconds": dt}
 
 
+def kernel_source_hash():
+    """Hash of every source the kernels are built from: the PMC counters in profiles/pmc_counters.json describe one build."""
+    import hashlib
+
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "rust_raytracer_amd", "csrc")
+    names = sorted(n for n in os.listdir(csrc) if n.endswith((".hip", ".hpp")))
+    for n in names + [os.path.join("..", "build.py"), os.path.join("..", "..", "include", "rrt.h")]:
+        with open(os.path.join(csrc, n), "rb") as f:
+            h.update(n.encode() + b"\0" + f.read() + b"\0")
+    return h.hexdigest()[:16]
+
+
 def pmc_record(name):
+    """(record, stale reason or None): the counters of the named workload, and whether they describe the kernels of this tree."""
     path = os.path.join(ROOT, "profiles", "pmc_counters.json")
     if not os.path.exists(path):
-        return None
+        return None, "profiles/pmc_counters.json is missing"
     with open(path) as f:
-        return json.load(f).get(name)
+        rec = json.load(f).get(name)
+    if rec is None:
+        return None, "no counters recorded for this workload"
+    now = kernel_source_hash()
+    if rec.get("kernel_source_hash") != now:
+        return rec, "counters were collected for kernel sources %s, this tree's are %s: collect them again (tools/profile_round.sh, tools/pmc_to_json.py)" % (
+            rec.get("kernel_source_hash"), now)
+    return rec, None
 
 
 def main():
@@ -74,9 +99,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", choices=["headline", "c5"], default="headline",
-                    help="headline: Cornell box with the glass sphere 1024x1024 @ 1024 spp; c5: the 10 M-triangle mesh at 3840x2160 @ 16 spp per step")
-    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU per step (default: 1024 for the headline config, 16 for c5)")
+    ap.add_argument("--config", choices=["headline", "c4", "c5"], default="headline",
+                    help="headline: Cornell box with the glass sphere 1024x1024 @ 1024 spp; c4: Globe.json 3840x2160 @ 2048 spp, sky background; "
+                         "c5: the 10 M-triangle mesh at 3840x2160 @ 16 spp per step")
+    ap.add_argument("--spp", type=int, default=0, help="samples per pixel per GPU per step (default: 1024 for the headline config, 2048 for c4, 16 for c5)")
     ap.add_argument("--shard", choices=["samples", "tiles"], default="samples")
     ap.add_argument("--cpu-spp", type=int, default=96, help="samples per pixel of the CPU-oracle sample (0 = skip); 96 spp is about 20 s on 16 cores")
     ap.add_argument("--aabb", choices=["tight", "reference"], default="tight")
@@ -113,7 +139,21 @@ def main():
 
     note("joined the group")
     c5 = args.config == "c5"
-    if c5:
+    background = rrt.BG_BLACK
+    data = "the reference's own scene file (assets/Cornell_Box_With_Sphere.json) at the benchmark's resolution; no dataset involved"
+    if args.config == "c4":
+        W, H = 3840, 2160
+        spp = args.spp or 2048
+        background = rrt.BG_SKY  # the scene has no emitter: black would give a black frame (main.rs:259-270)
+        globe = os.path.join(ROOT, "tests", "golden", "assets", "Globe.json")
+        host = rrt.HostScene.load(globe, width=W, height=H, samples=spp, aspect_ratio=16.0 / 9.0)
+        build_s = sum(host.times())
+        scene = rrt.Scene(host)
+        workload = "assets/Globe.json %dx%d @ %d spp per GPU per step, aspect ratio 16:9, sky background" % (W, H, spp)
+        bytes_per_ray = float(BYTES_PER_RAY)
+        data = "the reference's own scene file (assets/Globe.json with its two earth textures) at the benchmark's resolution"
+    elif c5:
+        data = "synthetic (seeded displaced-grid mesh, generated at run time)"
         import synth
 
         W, H = 3840, 2160
@@ -154,11 +194,13 @@ def main():
         """Render arguments of this rank: weak = `total_spp` samples of its own range; strong = its share of ONE `total_spp` frame."""
         if kind == "weak-samples":
             first, count = shard.sample_range(rank, total_spp)
-            return dict(samples=count, first_sample=first, seed=0, aabb_mode=aabb), total_spp * world
+            return dict(samples=count, first_sample=first, seed=0, aabb_mode=aabb, background=background), total_spp * world
         if kind == "strong-samples":
             first, count = shard.split_samples(rank, world, total_spp)
-            return dict(samples=count, first_sample=first, seed=0, aabb_mode=aabb), total_spp
-        return dict(samples=total_spp, first_sample=0, seed=0, aabb_mode=aabb, tile_count=world, tile_index=rank), total_spp
+            return dict(samples=count, first_sample=first, seed=0, aabb_mode=aabb, background=background), total_spp
+        if kind == "solo":  # rank 0 renders the whole frame, the others add nothing: the one-GPU time the strong figures are held against
+            return dict(samples=total_spp if rank == 0 else 0, first_sample=0, seed=0, aabb_mode=aabb, background=background), total_spp
+        return dict(samples=total_spp, first_sample=0, seed=0, aabb_mode=aabb, background=background, tile_count=world, tile_index=rank), total_spp
 
     def step(kw, frame_spp, tiles, ev0=None, ev1=None):
         with torch.cuda.stream(render_stream):
@@ -219,20 +261,28 @@ def main():
     trace_ms, accumulate_ms, passes = scene.kernel_times()
 
     strong = None
-    if world > 1 and not c5:
+    if world > 1:
         strong = {}
+        solo_s, _, _, _, _ = timed("solo", spp, args.steps, 1, False)
+        solo_ms = solo_s / max(args.steps, 1) * 1e3
         for kind in ("strong-samples", "tiles"):
             e, r, p, _, _ = timed(kind, spp, args.steps, 1, False)
-            strong[kind.replace("strong-", "")] = {"ms_per_frame": e / max(args.steps, 1) * 1e3, "value": r / e / 1e6, "unit": "Mrays/s",
+            ms = e / max(args.steps, 1) * 1e3
+            strong[kind.replace("strong-", "")] = {"ms_per_frame": ms, "value": r / e / 1e6, "unit": "Mrays/s",
+                                                   "one_gpu_ms_per_frame": solo_ms, "efficiency_vs_1gpu": solo_ms / (world * ms),
                                                    "frame": "%dx%d @ %d spp in total, divided over %d GPUs" % (W, H, spp, world)}
         scene.kernel_times()
 
-    # the 8-bit frame's way to the host: part of time-to-image, not of `value`
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    host_rgb8.copy_(rgb8, non_blocking=True)
-    torch.cuda.synchronize()
-    d2h_ms = (time.perf_counter() - t0) * 1e3
+    # the 8-bit frame's way to the host: part of time-to-image, not of `value`.  The process's first copy into a pinned buffer also
+    # pays for mapping that buffer to the device (milliseconds); later copies of the same 3 MB take a tenth of a millisecond.
+    d2h = []
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        host_rgb8.copy_(rgb8, non_blocking=True)
+        torch.cuda.synchronize()
+        d2h.append((time.perf_counter() - t0) * 1e3)
+    d2h_ms, d2h_warm_ms = d2h
 
     if rank == 0:
         launches = max(passes, 1)  # one path-tracer launch per pass of the staging buffer
@@ -240,35 +290,35 @@ def main():
         k_s = trace_ms / launches * 1e-3
         nominal = rays_per_launch * bytes_per_ray / k_s / 1e9
         step_ms = elapsed / max(args.steps, 1) * 1e3
-        pmc = pmc_record("c5" if c5 else "headline")
-        roofline = {"kernel": "k_trace_stream" if c5 else "k_trace_pool", "kernel_ms": k_s * 1e3, "launches_per_step": launches / max(args.steps, 1),
-                    "rays_per_launch": rays_per_launch, "accumulate_ms_per_step": accumulate_ms / max(args.steps, 1),
+        pmc, stale = pmc_record(args.config)
+        if pmc is not None and not (pmc.get("spp") == spp and pmc.get("width") == W):
+            stale = "counters were collected at %s x ... @ %s spp, this run is %d @ %d" % (pmc.get("width"), pmc.get("spp"), W, spp)
+        fresh = pmc is not None and stale is None
+        # The contract's figure: the workload model's bytes per ray x rays / kernel time against the HBM peak.
+        roofline = {"kernel": "k_trace_stream" if c5 else "k_trace_pool", "bound": "hbm", "achieved": nominal, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": nominal / HBM_PEAK_GBS, "traffic": pmc.get("hbm_bytes_per_launch") if fresh else None,
+                    "kernel_ms": k_s * 1e3, "launches_per_step": launches / max(args.steps, 1), "rays_per_launch": rays_per_launch,
+                    "bytes_per_ray": bytes_per_ray, "accumulate_ms_per_step": accumulate_ms / max(args.steps, 1),
                     "render_ms_per_step": float(np.mean(render_ms)) if render_ms else None,
-                    "nominal_hbm_achieved": nominal, "nominal_hbm_frac": nominal / HBM_PEAK_GBS, "bytes_per_ray": bytes_per_ray, "traffic": None}
-        if pmc and pmc.get("spp") == spp and pmc.get("width") == W:
-            roofline["traffic"] = pmc.get("hbm_bytes_per_launch")  # PMC passes of the same command, corrected for gfx950
+                    "kernel_source_hash": kernel_source_hash()}
+        if fresh:
             roofline["counters_from"] = pmc.get("source")
-        if c5:
-            roofline.update({"bound": "hbm", "achieved": nominal, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": nominal / HBM_PEAK_GBS})
-            if pmc:
-                roofline["hbm_traffic_frac"] = pmc.get("hbm_bytes_per_launch", 0.0) / k_s / 1e9 / HBM_PEAK_GBS
+            roofline["hbm_traffic_frac"] = pmc.get("hbm_bytes_per_launch", 0.0) / k_s / 1e9 / HBM_PEAK_GBS
         else:
-            roofline["bound"] = "valu"
-            roofline["unit"] = "Gwave-instr/s"
-            roofline["peak"] = VALU_PEAK_GINSTR
-            if pmc and pmc.get("valu_wave_instr_per_ray"):
+            roofline["counters_stale"] = stale
+        if not c5:
+            roofline["achieved_is"] = ("algorithmic bytes: 192 B per ray is what a tracer with its ray queues in HBM would move; this kernel keeps path state "
+                                       "on chip and moves `traffic` instead, so its real limiter is vector-ALU issue: see `valu`")
+            if fresh and pmc.get("valu_wave_instr_per_ray"):
                 per_ray = pmc["valu_wave_instr_per_ray"]
-                achieved = rays_per_launch * per_ray / k_s / 1e9
-                roofline.update({"achieved": achieved, "frac": achieved / VALU_PEAK_GINSTR, "valu_issue_frac": achieved / VALU_PEAK_GINSTR,
-                                 "valu_wave_instr_per_ray": per_ray, "lane_utilisation": pmc.get("lane_utilisation"),
-                                 "salu_instr_per_ray": pmc.get("salu_instr_per_ray"), "valu_busy_frac": pmc.get("valu_busy_frac"),
-                                 "valu_cycles_per_instruction": pmc.get("valu_cycles_per_instruction")})
-            else:
-                roofline.update({"achieved": None, "frac": None})
-            roofline["limiter"] = ("vector ALU: `peak` is one wave instruction per 2 cycles per SIMD (plain f32 multiply-add), but this kernel's mix "
-                                   "(packed f32, scalar operands, compares, selects, min/max, reciprocal, square root) costs valu_cycles_per_instruction on "
-                                   "average, and with that mix the ALU is busy valu_busy_frac of the launch; the 192 B/ray figure (nominal_hbm_*) is what a "
-                                   "queue-based tracer would move, this kernel moves about 5 B/ray (traffic)")
+                issued = rays_per_launch * per_ray / k_s / 1e9
+                roofline["valu"] = {"unit": "Gwave-instr/s", "peak": VALU_PEAK_GINSTR, "achieved": issued, "issue_frac": issued / VALU_PEAK_GINSTR,
+                                    "wave_instr_per_ray": per_ray, "lane_utilisation": pmc.get("lane_utilisation"),
+                                    "salu_instr_per_ray": pmc.get("salu_instr_per_ray"), "busy_frac": pmc.get("valu_busy_frac"),
+                                    "cycles_per_instruction": pmc.get("valu_cycles_per_instruction"),
+                                    "note": "`peak` is one wave instruction per 2 cycles per SIMD (plain f32 multiply-add); this kernel's mix (packed f32, "
+                                            "scalar operands, compares, selects, min/max, reciprocal, square root) costs cycles_per_instruction on average, "
+                                            "and with that mix the ALU is busy busy_frac of the launch"}
         out = {
             "metric": "Mrays/sec (whole node) + time-to-image, Cornell box 1024^2 @1024 spp",
             "value": rays_total / elapsed / 1e6,
@@ -281,18 +331,19 @@ def main():
             "scaling": "weak" if args.shard == "samples" else "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": data,
             "config": {"workload": workload,
                        "shard": "sample ranges, one RCCL reduce per step" if args.shard == "samples" else "interleaved 32x32 tiles, one RCCL reduce per step",
                        "value_is": "weak scaling: every GPU traces %d spp of its own, the frame has %d spp" % (spp, spp * world) if args.shard == "samples"
                                    else "strong scaling: one %d-spp frame divided into interleaved tiles" % spp,
-                       "background": "black", "seed": 0, "aabb_mode": args.aabb, "max_depth": 50,
+                       "background": "sky" if background == rrt.BG_SKY else "black", "seed": 0, "aabb_mode": args.aabb, "max_depth": 50,
                        "samples_per_second": paths_total / elapsed, "rays_per_path": rays_total / max(paths_total, 1),
                        "time_to_image_ms": upload_ms + step_ms + d2h_ms,
                        "time_to_image_parts_ms": {"scene_upload": upload_ms, "render_reduce_resolve": step_ms, "rgb8_to_host": d2h_ms,
                                                   "host_load_and_build_not_included": build_s * 1e3,
-                                                  "scene_upload_in_a_warm_process": upload_warm_ms},
-                       "time_to_image_warm_ms": upload_warm_ms + step_ms + d2h_ms},
+                                                  "scene_upload_in_a_warm_process": upload_warm_ms, "rgb8_to_host_in_a_warm_process": d2h_warm_ms,
+                                                  "scene_upload_parts": scene.upload_parts()},
+                       "time_to_image_warm_ms": upload_warm_ms + step_ms + d2h_warm_ms},
             "roofline": roofline,
         }
         if strong is not None:
@@ -300,7 +351,7 @@ def main():
         if rehearsal:
             out["config"]["rehearsal"] = ("%d ranks on %d GPU(s) over gloo: the ranks share a GPU, so `value` and the strong-scaling figures only show "
                                           "that the N > 1 path runs (render stream -> event -> collective -> resolve), not how it scales" % (world, n_devices))
-        if world == 1 and args.cpu_spp > 0 and not c5:
+        if world == 1 and args.cpu_spp > 0 and args.config == "headline":
             threads = min(len(os.sched_getaffinity(0)), 16)
             out["cpu_baseline"] = cpu_baseline(args.cpu_spp, threads)
             two = cpu_baseline(max(args.cpu_spp // 8, 1), 2)  # the reference's default thread count (main.rs:66-72)

@@ -296,6 +296,12 @@ int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out);
 void rrt_scene_destroy(rrt_scene*);
 /* Host wall-clock seconds rrt_scene_create took (pairing the leaves' triangles, primitive boxes, the copies to HBM). */
 int rrt_scene_upload_seconds(const rrt_scene*, double* seconds);
+/* The parts of that time, in seconds (any pointer may be NULL): the first call that needs the device (a process that has not used
+ * the GPU before creates its context there), the first access to the library's code object (the runtime loads it onto the device at
+ * that moment), the host-side preparation (validation, pairing, boxes, tables), and the device allocations and copies.  Only a
+ * process's first handle on a device pays the first two.  ≙ nothing in the reference, whose `Took {} seconds` (main.rs:64, 191) is
+ * one number. */
+int rrt_scene_upload_breakdown(const rrt_scene*, double* first_device_call, double* code_object, double* host_preparation, double* copies);
 
 /* ≙ Aggregate::hit (aggregate.rs:118-124) for n rays: closest hit in (t_min, t_max).
  * o_xyz, d_xyz: n*3 floats.  prim_id[i] = shape index in scene order or -1; t_hit[i] = distance (t_max on miss).
@@ -339,6 +345,8 @@ int rrt_render_multi(rrt_scene* const* scenes, uint32_t n, uint32_t shard_mode, 
  * A frame whose samples do not all fit is traced in several passes.  Limits: width * height * 12 bytes must not exceed RRT_NOALLOC_STAGING_BYTES (11 184 810 pixels), else
  * RRT_ERR_LIMIT; rrt_scene_set_timing does not cover these renders.  All calls on one GPU share that GPU's area: calls that
  * overlap in time on one GPU (different streams or scene handles) race; calls on one stream, or ordered by events, do not.
+ * The first call on a GPU brings that GPU's copy of the area into being (the runtime loads the area's code object then, about
+ * 45 ms, and allocates while it does): a caller that must not allocate makes one call during set-up.
  * Like every render entry point it also uses the handle's work-item counters (zeroed on `stream` before each launch): two renders
  * of ONE handle must be ordered on the device whichever entry point they use, or they skip and duplicate work items. */
 #define RRT_NOALLOC_STAGING_BYTES (128u << 20)

@@ -278,6 +278,7 @@ extern "C" {
     pub fn rrt_scene_create_on(desc: *const rrt_scene_desc, device: c_int, out: *mut *mut rrt_scene) -> c_int;
     pub fn rrt_scene_destroy(s: *mut rrt_scene);
     pub fn rrt_scene_upload_seconds(s: *const rrt_scene, seconds: *mut f64) -> c_int;
+    pub fn rrt_scene_upload_breakdown(s: *const rrt_scene, first_device_call: *mut f64, code_object: *mut f64, host_preparation: *mut f64, copies: *mut f64) -> c_int;
     pub fn rrt_device_count(count: *mut c_int) -> c_int;
     /// ≙ `Aggregate::hit` (aggregate.rs:118-124) for n rays
     pub fn rrt_intersect_batch(s: *mut rrt_scene, o_xyz: *const f32, d_xyz: *const f32, n: usize, t_min: f32, t_max: f32, aabb_mode: u32, seed: u32,

@@ -139,6 +139,7 @@ def lib():
     L.rrt_scene_destroy.argtypes = [vp]
     L.rrt_scene_create_on.argtypes = [C.POINTER(_SceneDesc), C.c_int, C.POINTER(vp)]
     L.rrt_scene_upload_seconds.argtypes = [vp, C.POINTER(C.c_double)]
+    L.rrt_scene_upload_breakdown.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
     L.rrt_device_count.argtypes = [C.POINTER(C.c_int)]
     L.rrt_render_multi.argtypes = [C.POINTER(vp), C.c_uint32, C.c_uint32, C.POINTER(_RenderParams), vp, C.POINTER(_Stats)]
     L.rrt_intersect_batch.argtypes = [vp, vp, vp, C.c_size_t, C.c_float, C.c_float, C.c_uint32, C.c_uint32, vp, vp]
@@ -336,6 +337,13 @@ class Scene:
         t = C.c_double(0)
         _check(lib().rrt_scene_upload_seconds(self._h, C.byref(t)))
         return t.value
+
+    def upload_parts(self):
+        """What rrt_scene_create's time went to, in ms: the first device call of the process (context), the first access to the
+        library's code object (its load onto the device), host-side preparation, device allocations and copies."""
+        v = [C.c_double(0) for _ in range(4)]
+        _check(lib().rrt_scene_upload_breakdown(self._h, *[C.byref(x) for x in v]))
+        return {"first_device_call": v[0].value * 1e3, "code_object": v[1].value * 1e3, "host_preparation": v[2].value * 1e3, "allocations_and_copies": v[3].value * 1e3}
 
     @classmethod
     def load(cls, path, width=0, height=0, samples=0, aspect_ratio=float("nan"), tree="BVH"):

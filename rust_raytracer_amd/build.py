@@ -9,7 +9,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librrt_hip.so")
 CLI = os.path.join(HERE, "rust-raytracer")
 
-SOURCES = ["rrt_api.hip", "rrt_stream.hip", "rrt_bvh_build.hip", "rrt_error.cpp", "rrt_abi_layout.cpp", "host/scene_host.cpp", "host/scene_json.cpp", "host/image_io.cpp", "host/image_codecs.cpp"]
+SOURCES = ["rrt_api.hip", "rrt_stream.hip", "rrt_bvh_build.hip", "rrt_noalloc_area.hip", "rrt_error.cpp", "rrt_abi_layout.cpp", "host/scene_host.cpp", "host/scene_json.cpp", "host/image_io.cpp", "host/image_codecs.cpp"]
 HEADERS = ["cli/main.cpp", "rrt_device.hpp", "rrt_launch.hpp", "rrt_math.hpp", "rrt_scene_view.hpp", "rrt_primitives.hpp", "rrt_profile.hpp", "rrt_traversal.hpp", "rrt_shading.hpp", "rrt_error.hpp", "rrt_bvh_build.hpp", "host/scene_host.hpp", "host/hmath.hpp", "../../include/rrt.h"]
 
 # -ffp-contract=off: the reference never fuses a*b+c; bit-exact hit decisions need unfused f32 on host and device.

@@ -21,12 +21,7 @@ using namespace rrt;
 
 namespace {
 
-// Staging area of rrt_render_device_noalloc: the per-sample radiance slab of a render pass, held in the code object itself
-// so that the entry point never asks the runtime for memory.  Each GPU the library runs on holds its own copy until the
-// process ends.  In host code the array's NAME is only a handle for hipGetSymbolAddress; kernels, here as everywhere, get the
-// address that call returned for the current device (rrt_scene::static_slab).
-constexpr size_t kStaticSlabBytes = RRT_NOALLOC_STAGING_BYTES;
-static __device__ __align__(256) unsigned char scratch[kStaticSlabBytes];
+constexpr size_t kStaticSlabBytes = RRT_NOALLOC_STAGING_BYTES;  // the staging area of rrt_render_device_noalloc (rrt_noalloc_area.hip)
 
 
 // ---- the trace kernel for shallow trees (at most kDeepTreeNodes nodes; deep trees: k_trace_stream) ------------------------
@@ -578,15 +573,18 @@ __global__ void k_selftest_rcp(unsigned long long* __restrict__ mismatches) {
         if (e_ != hipSuccess) return rrt_set_error(RRT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
+thread_local double t_copy_seconds = 0.0;  // rrt_scene_create: the time its device allocations and copies have taken so far
 template <typename T>
 int upload(const T* src, size_t count, const void** dst, std::vector<void*>* owned) {
     *dst = nullptr;
     size_t bytes = count * sizeof(T);
     void* p = nullptr;
+    const auto t0 = std::chrono::steady_clock::now();
     // keep every pointer valid (kernels may form addresses for empty arrays but never dereference them)
     HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
     owned->push_back(p);
     if (bytes) HIP_TRY(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+    t_copy_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     *dst = p;
     return RRT_OK;
 }
@@ -597,7 +595,6 @@ struct rrt_scene {
     DScene d{};
     std::vector<void*> owned;
     float* slab = nullptr;  // per-sample radiance staging, allocated on first render
-    float* static_slab = nullptr;  // this device's copy of `scratch` (rrt_render_device_noalloc), looked up once in rrt_scene_create
     uint32_t* d_items = nullptr;   // item counters of the persistent kernels (k_trace_pool: one word; k_trace_stream: eight, one per XCD band), zeroed on the stream before every launch
     uint32_t wave_places = 0;      // k_trace_pool: waves the device holds at kPoolWaves per SIMD (the persistent grid's size)
     bool pooling = true;           // shallow plain scenes take k_trace_pool (rrt_scene_set_pooling)
@@ -612,6 +609,7 @@ struct rrt_scene {
     uint32_t n_spheres = 0, n_media = 0, n_btris = 0, n_materials = 0, n_textures = 0;
     int device = 0;
     double upload_seconds = 0.0;  // host wall clock of rrt_scene_create
+    double upload_parts[4] = {0.0, 0.0, 0.0, 0.0};  // of which: the first device call | the code object | host-side preparation | allocations and copies
     uint64_t desc_hash = 0;       // of the description's arrays and camera (rrt_render_multi compares its handles)
     // optional per-kernel timing: three events per pass (before k_trace, between the kernels, after k_accumulate)
     bool timing = false;
@@ -993,13 +991,19 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     struct Destroy { void operator()(rrt_scene* p) const { rrt_scene_destroy(p); } };
     std::unique_ptr<rrt_scene, Destroy> owner(new rrt_scene());
     rrt_scene* s = owner.get();
+    // Where a process's first handle spends its time: the first call that needs the device (a process that has not used the GPU yet
+    // creates its context here), then the first access to something in this library's code object (the runtime loads the code object
+    // onto the device at that moment: every kernel variant of this translation unit and the 128 MiB staging area).
+    const auto t_validated = std::chrono::steady_clock::now();
     HIP_TRY(hipGetDevice(&s->device));
+    HIP_TRY(hipFree(nullptr));
+    const auto t_context = std::chrono::steady_clock::now();
     {
-        // every GPU holds its own copy of the array at its own address: ask for the current device's, once, here
-        void* p = nullptr;
-        HIP_TRY(hipGetSymbolAddress(&p, HIP_SYMBOL(scratch)));
-        s->static_slab = (float*)p;
+        hipFuncAttributes attr;  // (asks the runtime about one of this file's kernels: that loads the file's code object)
+        HIP_TRY(hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&k_resolve)));
     }
+    const auto t_code = std::chrono::steady_clock::now();
+    t_copy_seconds = 0.0;
     uint32_t clean_depth = 0;  // clean trees: most stack entries a walk can have pending (sizes the traversal stack)
 #define UP(field, src, count)                                                        \
     do {                                                                             \
@@ -1408,7 +1412,12 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
         mix(&desc->aggregate_kind, sizeof desc->aggregate_kind);
         s->desc_hash = h;
     }
-    s->upload_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - started).count();
+    const auto t_done = std::chrono::steady_clock::now();
+    s->upload_seconds = std::chrono::duration<double>(t_done - started).count();
+    s->upload_parts[0] = std::chrono::duration<double>(t_context - t_validated).count();
+    s->upload_parts[1] = std::chrono::duration<double>(t_code - t_context).count();
+    s->upload_parts[3] = t_copy_seconds;
+    s->upload_parts[2] = s->upload_seconds - s->upload_parts[0] - s->upload_parts[1] - s->upload_parts[3];
     *out = owner.release();
     return RRT_OK;
 }
@@ -1437,6 +1446,15 @@ int rrt_device_count(int* count) {
 int rrt_scene_upload_seconds(const rrt_scene* s, double* seconds) {
     if (!s || !seconds) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_upload_seconds: NULL argument");
     *seconds = s->upload_seconds;
+    return RRT_OK;
+}
+
+int rrt_scene_upload_breakdown(const rrt_scene* s, double* first_device_call, double* code_object, double* host_preparation, double* copies) {
+    if (!s) return rrt_set_error(RRT_ERR_INVALID, "rrt_scene_upload_breakdown: NULL scene");
+    if (first_device_call) *first_device_call = s->upload_parts[0];
+    if (code_object) *code_object = s->upload_parts[1];
+    if (host_preparation) *host_preparation = s->upload_parts[2];
+    if (copies) *copies = s->upload_parts[3];
     return RRT_OK;
 }
 
@@ -1594,8 +1612,8 @@ static int plan_render(rrt_scene* s, const rrt_render_params* p, RenderPlan* pla
 }
 
 // Enqueues the passes of one render.  static_staging = false: the slab is the scene handle's own buffer, (re)allocated here when
-// the frame needs more; true: the slab is the current device's copy of `scratch` and nothing here allocates, frees or creates
-// anything (no event is recorded either: the per-kernel timing of rrt_scene_set_timing does not cover these renders).
+// the frame needs more; true: the slab is the current device's copy of the built-in staging area (rrt_noalloc_area.hip) and nothing
+// here allocates, frees or creates anything (no event is recorded either: the per-kernel timing of rrt_scene_set_timing does not cover these renders).
 static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_sum, uint64_t* d_counters, void* stream, bool static_staging) {
     RenderPlan plan;
     int rc = plan_render(s, p, &plan);
@@ -1618,9 +1636,9 @@ static int render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_
     const uint64_t n_passes = (plan.spp + per_pass - 1) / per_pass;
     const uint64_t even = ((plan.spp + n_passes - 1) / n_passes + kChunk - 1) / kChunk * kChunk;
     if (even < per_pass) per_pass = even;
-    float* const slab = static_staging ? s->static_slab : nullptr;
+    float* slab = nullptr;
     if (static_staging) {
-        if (!slab) return rrt_set_error(RRT_ERR_DEVICE, "rrt_render_device_noalloc: the built-in staging area was not found on this device");
+        if (int rc2 = noalloc_area(s->device, &slab)) return rc2;
     } else if (s->slab_bytes < (size_t)per_pass * frame_bytes) {
         if (s->slab) {
             HIP_TRY(hipDeviceSynchronize());  // earlier renders on any stream may still read the old buffer

@@ -52,6 +52,9 @@ hipError_t launch_trace_stream(int mode, uint32_t features, dim3 grid, size_t ld
 hipError_t launch_intersect_stream(int mode, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const float* o, const float* d, size_t n, float t_min,
                                    float t_max, uint32_t seed, uint32_t lds_entries, uint32_t run, uint32_t coop_lanes, int* prim, float* t_hit);
 
+// The current device's copy of the built-in staging area of rrt_render_device_noalloc (rrt_noalloc_area.hip); returns an RRT_* code.
+int noalloc_area(int device, float** out);
+
 #ifdef RRT_PHASE_PROFILE
 // profiling build only: reads and clears the counters of the deep-tree kernels
 hipError_t profile_take_stream(uint64_t* out8);
