@@ -204,8 +204,6 @@ def main():
 
     def step(kw, frame_spp, tiles, ev0=None, ev1=None):
         with torch.cuda.stream(render_stream):
-            if tiles:
-                img.zero_()
             if ev0 is not None:
                 ev0.record(render_stream)
             if kw["samples"] > 0:
@@ -217,7 +215,12 @@ def main():
             rendered.record(render_stream)
         cur = torch.cuda.current_stream()
         cur.wait_event(rendered)  # the collective below is enqueued behind the render explicitly, not by stream coincidence
-        shard.reduce_frame(img, dst=0)  # the one collective of the job (no-op on one GPU)
+        # the one collective of the job (no-op on one GPU): sample ranges are summed, tiles - each rank's own pixels, packed: an
+        # N-th of the frame per rank - are gathered and put in place
+        if tiles:
+            shard.gather_tiles(img, dst=0)
+        else:
+            shard.reduce_frame(img, dst=0)
         if rank == 0:  # time-to-image ends with the 8-bit frame (main.rs:173-186), still in HBM
             rrt.resolve_rgb8_device(img.data_ptr(), W, H, frame_spp, rgb8.data_ptr(), cur.cuda_stream)
         render_stream.wait_stream(cur)  # the next step's render must not overwrite the frame under the reduce / resolve
@@ -333,7 +336,7 @@ def main():
             "dtype": "f32",
             "data": data,
             "config": {"workload": workload,
-                       "shard": "sample ranges, one RCCL reduce per step" if args.shard == "samples" else "interleaved 32x32 tiles, one RCCL reduce per step",
+                       "shard": "sample ranges, one RCCL reduce per step" if args.shard == "samples" else "interleaved 32x32 tiles, one RCCL gather of the ranks' own pixels per step",
                        "value_is": "weak scaling: every GPU traces %d spp of its own, the frame has %d spp" % (spp, spp * world) if args.shard == "samples"
                                    else "strong scaling: one %d-spp frame divided into interleaved tiles" % spp,
                        "background": "sky" if background == rrt.BG_SKY else "black", "seed": 0, "aabb_mode": args.aabb, "max_depth": 50,

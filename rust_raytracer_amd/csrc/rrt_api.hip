@@ -9,6 +9,7 @@
 #include <cstring>
 #include <limits>
 #include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -591,8 +592,24 @@ int upload(const T* src, size_t count, const void** dst, std::vector<void*>* own
 
 }  // namespace
 
+// What rrt_render_multi keeps per scene handle from call to call: the handle's frame, counters, packed tiles, stream and events on
+// the handle's own device, and the buffer its share lands in on the first handle's device.
+struct MultiState {
+    float* d_img = nullptr;
+    size_t img_bytes = 0;
+    uint64_t* d_cnt = nullptr;
+    float* d_pack = nullptr;
+    size_t pack_bytes = 0;
+    float* landing = nullptr;
+    size_t landing_bytes = 0;
+    int landing_device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t begin = nullptr, end = nullptr, landed = nullptr;
+};
+
 struct rrt_scene {
     DScene d{};
+    MultiState multi;
     std::vector<void*> owned;
     float* slab = nullptr;  // per-sample radiance staging, allocated on first render
     uint32_t* d_items = nullptr;   // item counters of the persistent kernels (k_trace_pool: one word; k_trace_stream: eight, one per XCD band), zeroed on the stream before every launch
@@ -1503,6 +1520,22 @@ int rrt_scene_kernel_times(rrt_scene* s, double* trace_ms, double* accumulate_ms
 
 void rrt_scene_destroy(rrt_scene* s) {
     if (!s) return;
+    int before = -1;
+    (void)hipGetDevice(&before);
+    MultiState& m = s->multi;
+    if (m.landing) {  // (lives on the first handle's device)
+        (void)hipSetDevice(m.landing_device);
+        (void)hipFree(m.landing);
+    }
+    (void)hipSetDevice(s->device);
+    if (m.stream) (void)hipStreamSynchronize(m.stream);
+    (void)hipFree(m.d_img);
+    (void)hipFree(m.d_cnt);
+    (void)hipFree(m.d_pack);
+    for (hipEvent_t e : {m.begin, m.end, m.landed})
+        if (e) (void)hipEventDestroy(e);
+    if (m.stream) (void)hipStreamDestroy(m.stream);
+    if (before >= 0) (void)hipSetDevice(before);
     for (void* p : s->owned) (void)hipFree(p);
     if (s->slab) (void)hipFree(s->slab);
     for (hipEvent_t e : s->events) (void)hipEventDestroy(e);
@@ -1864,20 +1897,16 @@ int rrt_render(rrt_scene* s, const rrt_render_params* p, float* rgb_sum, rrt_sta
 
 // ---- several GPUs in one process ------------------------------------------------------------------------------------------
 // ≙ main.rs:136-165 (N worker threads, one colour buffer).  One host thread per scene handle: it makes the handle's device
-// current, traces that device's share into a frame in that device's HBM and records an event.  The first device then gathers:
-// frame i is copied into a landing buffer on device 0 (hipMemcpyPeerAsync, each peer over its own xGMI link, on a stream of
-// its own so the copies overlap) and, in device order, added to device 0's frame (sample ranges) or its owner's tiles are
-// taken over (tiles), one float per thread.
+// current, traces that device's share into a frame in that device's HBM and, on the same stream and therefore as soon as that
+// device's render is done (no device waits for a slower one), PUSHES its share into a landing buffer on the first device
+// (hipMemcpyPeerAsync; peer access between the two devices is switched on once, so the copy is one device writing into the other's
+// memory over their xGMI link).  Sample ranges move the whole frame, tiles only the owner's tiles, packed (an N-th of the frame).
+// The first device then, in device order, adds the landed frames to its own (sample ranges) or unpacks the tiles into it, one float
+// per thread.  Frames, landing buffers, streams and events belong to the scene handles and are kept from call to call.
 namespace {
 struct MultiWorker {
     rrt_scene* scene = nullptr;
     rrt_render_params params{};
-    float* d_img = nullptr;       // on scene->device
-    uint64_t* d_cnt = nullptr;    // on scene->device
-    float* d_landing = nullptr;   // on the first device (workers 1..n-1)
-    hipStream_t stream = nullptr;       // on scene->device
-    hipStream_t copy_stream = nullptr;  // on the first device
-    hipEvent_t begin = nullptr, end = nullptr, landed = nullptr;
     size_t mark = 0;
     bool user_timing = false;
     int rc = RRT_OK;
@@ -1885,6 +1914,7 @@ struct MultiWorker {
     uint64_t counters[2] = {0, 0};
     double render_s = 0.0, trace_s = 0.0, accumulate_s = 0.0;
 };
+constexpr uint32_t kTileFloats = 32u * 32u * 3u;
 }  // namespace
 
 __global__ void k_add_frame(float* __restrict__ into, const float* __restrict__ from, size_t n) {
@@ -1892,15 +1922,95 @@ __global__ void k_add_frame(float* __restrict__ into, const float* __restrict__ 
     if (i < n) into[i] = into[i] + from[i];
 }
 
-// Tile sharding: the pixels of the tiles device `tile_index` owns are taken over as they are (no arithmetic: the frame stays
-// bit-identical to a single device's).
-__global__ void k_take_tiles(float* __restrict__ into, const float* __restrict__ from, size_t n, uint32_t W, uint32_t tiles_x, uint32_t tile_count,
-                             uint32_t tile_index) {
+// Tile sharding.  Tile t of the frame (32x32 pixels, numbered row by row) belongs to device t % tile_count and is the (t / tile_count)-th
+// of that device's tiles; packed, a device's tiles lie one after the other, 32 x 32 x 3 floats each (pixels beyond the frame's edge
+// keep their place and are never written or read).  Pixels are taken over as they are: the frame stays bit-identical to one device's.
+__global__ void k_pack_tiles(const float* __restrict__ frame, float* __restrict__ packed, size_t n_packed, uint32_t W, uint32_t H, uint32_t tiles_x,
+                             uint32_t n_tiles, uint32_t tile_count, uint32_t tile_index) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const size_t pixel = i / 3;
-    const uint32_t x = (uint32_t)(pixel % W), y = (uint32_t)(pixel / W);
-    if (((y >> 5) * tiles_x + (x >> 5)) % tile_count == tile_index) into[i] = from[i];
+    if (i >= n_packed) return;
+    const uint32_t t = (uint32_t)(i / kTileFloats) * tile_count + tile_index, in_tile = (uint32_t)(i % kTileFloats);
+    const uint32_t x = (t % tiles_x) * 32u + (in_tile / 3u) % 32u, y = (t / tiles_x) * 32u + in_tile / 96u;
+    if (t < n_tiles && x < W && y < H) packed[i] = frame[((size_t)y * W + x) * 3 + in_tile % 3u];
+}
+__global__ void k_unpack_tiles(float* __restrict__ frame, const float* __restrict__ packed, size_t n_packed, uint32_t W, uint32_t H, uint32_t tiles_x,
+                               uint32_t n_tiles, uint32_t tile_count, uint32_t tile_index) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_packed) return;
+    const uint32_t t = (uint32_t)(i / kTileFloats) * tile_count + tile_index, in_tile = (uint32_t)(i % kTileFloats);
+    const uint32_t x = (t % tiles_x) * 32u + (in_tile / 3u) % 32u, y = (t / tiles_x) * 32u + in_tile / 96u;
+    if (t < n_tiles && x < W && y < H) frame[((size_t)y * W + x) * 3 + in_tile % 3u] = packed[i];
+}
+
+// One device writing into another's memory needs peer access switched on once per ordered pair (from -> to).
+static int enable_peer_access(int from, int to, bool* direct) {
+    static std::mutex lock;
+    static std::vector<std::pair<int, int>> done;  // pairs already handled, with what came of it in `direct_ok`
+    static std::vector<bool> direct_ok;
+    std::lock_guard<std::mutex> hold(lock);
+    for (size_t k = 0; k < done.size(); ++k)
+        if (done[k] == std::make_pair(from, to)) {
+            *direct = direct_ok[k];
+            return RRT_OK;
+        }
+    int can = 0;
+    HIP_TRY(hipDeviceCanAccessPeer(&can, from, to));
+    bool ok = false;
+    if (can) {
+        int before = -1;
+        HIP_TRY(hipGetDevice(&before));
+        HIP_TRY(hipSetDevice(from));
+        const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+        if (e == hipErrorPeerAccessAlreadyEnabled) (void)hipGetLastError();
+        ok = e == hipSuccess || e == hipErrorPeerAccessAlreadyEnabled;
+        (void)hipSetDevice(before);
+    }
+    done.emplace_back(from, to);
+    direct_ok.push_back(ok);  // (false: hipMemcpyPeerAsync still works, staged by the runtime)
+    *direct = ok;
+    return RRT_OK;
+}
+
+// Makes sure the handle's multi-GPU buffers can hold this call: its frame and counters on its own device, and - for every handle
+// but the first - what it pushes (on its own device: the packed tiles) and where that lands (on the first handle's device).
+static int multi_prepare(rrt_scene* s, size_t frame_bytes, size_t push_bytes, int first_device, bool is_first) {
+    MultiState& m = s->multi;
+    HIP_TRY(hipSetDevice(s->device));
+    if (!m.stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&m.stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreate(&m.begin));
+        HIP_TRY(hipEventCreate(&m.end));
+        HIP_TRY(hipEventCreate(&m.landed));
+        HIP_TRY(hipMalloc((void**)&m.d_cnt, 16));
+    }
+    if (m.img_bytes < frame_bytes) {
+        if (m.d_img) HIP_TRY(hipFree(m.d_img));
+        m.d_img = nullptr;
+        m.img_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&m.d_img, frame_bytes));
+        m.img_bytes = frame_bytes;
+    }
+    if (is_first) return RRT_OK;
+    if (m.pack_bytes < push_bytes) {
+        if (m.d_pack) HIP_TRY(hipFree(m.d_pack));
+        m.d_pack = nullptr;
+        m.pack_bytes = 0;
+        HIP_TRY(hipMalloc((void**)&m.d_pack, push_bytes));
+        m.pack_bytes = push_bytes;
+    }
+    if (m.landing_bytes < push_bytes || m.landing_device != first_device) {
+        if (m.landing) {
+            HIP_TRY(hipSetDevice(m.landing_device));
+            HIP_TRY(hipFree(m.landing));
+        }
+        m.landing = nullptr;
+        m.landing_bytes = 0;
+        HIP_TRY(hipSetDevice(first_device));
+        HIP_TRY(hipMalloc((void**)&m.landing, push_bytes));
+        m.landing_bytes = push_bytes;
+        m.landing_device = first_device;
+    }
+    return RRT_OK;
 }
 
 static int render_multi(rrt_scene* const* scenes, uint32_t n, uint32_t shard_mode, const rrt_render_params* p, float* rgb_sum, rrt_stats* stats) {
@@ -1924,10 +2034,20 @@ static int render_multi(rrt_scene* const* scenes, uint32_t n, uint32_t shard_mod
     const uint32_t spp = p->samples ? p->samples : scenes[0]->samples;
     if (W == 0 || H == 0) return rrt_set_error(RRT_ERR_INVALID, "rrt_render_multi: zero resolution");
     const size_t frame_floats = (size_t)W * H * 3, bytes = frame_floats * sizeof(float);
+    const uint32_t tiles_x = (W + 31) / 32, n_tiles = tiles_x * ((H + 31) / 32);
+    const bool tiles = shard_mode == RRT_SHARD_TILES;
     const bool accumulate = (p->flags & RRT_RENDER_ACCUMULATE) != 0;
     int caller_device = -1;
     HIP_TRY(hipGetDevice(&caller_device));
     const int first_device = scenes[0]->device;
+    struct Restore {  // whatever happens below, the caller's device and the handles' timing switches come back
+        int device;
+        std::vector<MultiWorker>* w;
+        ~Restore() {
+            for (MultiWorker& k : *w) k.scene->timing = k.user_timing;
+            (void)hipSetDevice(device);
+        }
+    };
 
     std::vector<MultiWorker> w(n);
     // shares: contiguous sample ranges (the remainder goes to the first devices, one sample each) or interleaved tiles
@@ -1935,13 +2055,14 @@ static int render_multi(rrt_scene* const* scenes, uint32_t n, uint32_t shard_mod
     uint32_t next_sample = p->first_sample;
     for (uint32_t i = 0; i < n; ++i) {
         w[i].scene = scenes[i];
+        w[i].user_timing = scenes[i]->timing;
         w[i].params = *p;
         w[i].params.width = W;
         w[i].params.height = H;
         // sample ranges: the caller's sums go into the first device's share only (the others' shares are added to it);
         // tiles: every device continues the sums of its own pixels
-        w[i].params.flags = (accumulate && (i == 0 || shard_mode == RRT_SHARD_TILES)) ? RRT_RENDER_ACCUMULATE : 0u;
-        if (shard_mode == RRT_SHARD_SAMPLES) {
+        w[i].params.flags = (accumulate && (i == 0 || tiles)) ? RRT_RENDER_ACCUMULATE : 0u;
+        if (!tiles) {
             const uint32_t mine = base + (i < extra ? 1u : 0u);
             w[i].params.samples = mine;
             w[i].params.first_sample = next_sample;
@@ -1952,99 +2073,84 @@ static int render_multi(rrt_scene* const* scenes, uint32_t n, uint32_t shard_mod
             w[i].params.tile_index = i;
         }
     }
-    auto release = [&]() {
-        for (MultiWorker& k : w) {
-            (void)hipSetDevice(k.scene->device);
-            if (k.stream) (void)hipStreamSynchronize(k.stream);
-            (void)hipFree(k.d_img);
-            (void)hipFree(k.d_cnt);
-            if (k.begin) (void)hipEventDestroy(k.begin);
-            if (k.end) (void)hipEventDestroy(k.end);
-            if (k.stream) (void)hipStreamDestroy(k.stream);
-            k.scene->timing = k.user_timing;
-            (void)hipSetDevice(first_device);
-            if (k.copy_stream) (void)hipStreamSynchronize(k.copy_stream);
-            (void)hipFree(k.d_landing);
-            if (k.landed) (void)hipEventDestroy(k.landed);
-            if (k.copy_stream) (void)hipStreamDestroy(k.copy_stream);
-        }
-        (void)hipSetDevice(caller_device);
+    Restore restore{caller_device, &w};
+    // what handle i pushes to the first device: its frame (sample ranges) or its tiles, packed
+    auto push_floats = [&](uint32_t i) -> size_t {
+        if (!tiles) return frame_floats;
+        const uint32_t owned = n_tiles > i ? (n_tiles - i + n - 1) / n : 0;
+        return (size_t)owned * kTileFloats;
     };
-#define MULTI_TRY(expr)                                                                                                      \
-    do {                                                                                                                     \
-        hipError_t e_ = (expr);                                                                                              \
-        if (e_ != hipSuccess) { release(); return rrt_set_error(RRT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
-    } while (0)
-    for (MultiWorker& k : w) k.user_timing = k.scene->timing;
-    // buffers: each device's frame and counters; on the first device one landing buffer per other frame
     for (uint32_t i = 0; i < n; ++i) {
-        MultiWorker& k = w[i];
-        MULTI_TRY(hipSetDevice(k.scene->device));
-        MULTI_TRY(hipMalloc((void**)&k.d_img, bytes));
-        MULTI_TRY(hipMalloc((void**)&k.d_cnt, 16));
-        MULTI_TRY(hipStreamCreateWithFlags(&k.stream, hipStreamNonBlocking));
-        MULTI_TRY(hipEventCreate(&k.begin));
-        MULTI_TRY(hipEventCreate(&k.end));
-        if (i > 0) {
-            MULTI_TRY(hipSetDevice(first_device));
-            MULTI_TRY(hipMalloc((void**)&k.d_landing, bytes));
-            MULTI_TRY(hipStreamCreateWithFlags(&k.copy_stream, hipStreamNonBlocking));
-            MULTI_TRY(hipEventCreate(&k.landed));
-        }
+        if (int rc = multi_prepare(scenes[i], bytes, std::max<size_t>(push_floats(i), 4) * sizeof(float), first_device, i == 0)) return rc;
+        bool direct = true;
+        if (i > 0 && scenes[i]->device != first_device)
+            if (int rc = enable_peer_access(scenes[i]->device, first_device, &direct)) return rc;
     }
-    hipEvent_t copy_in[2] = {nullptr, nullptr}, reduce_ev[2] = {nullptr, nullptr}, copy_out[2] = {nullptr, nullptr};
-    auto release_all = [&]() {
-        (void)hipSetDevice(first_device);
-        for (hipEvent_t e : {copy_in[0], copy_in[1], reduce_ev[0], reduce_ev[1], copy_out[0], copy_out[1]})
-            if (e) (void)hipEventDestroy(e);
-        release();
-    };
-#undef MULTI_TRY
-#define MULTI_TRY(expr)                                                                                                      \
-    do {                                                                                                                     \
-        hipError_t e_ = (expr);                                                                                              \
-        if (e_ != hipSuccess) { release_all(); return rrt_set_error(RRT_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_)); } \
-    } while (0)
-    MULTI_TRY(hipSetDevice(first_device));
-    for (hipEvent_t* e : {&copy_in[0], &copy_in[1], &reduce_ev[0], &reduce_ev[1], &copy_out[0], &copy_out[1]}) MULTI_TRY(hipEventCreate(e));
+    hipEvent_t ev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};  // copy in (2), reduce (2), copy out (2): on the first device
+    struct Events {
+        hipEvent_t* e;
+        int device;
+        ~Events() {
+            (void)hipSetDevice(device);
+            for (int k = 0; k < 6; ++k)
+                if (e[k]) (void)hipEventDestroy(e[k]);
+        }
+    } events{ev, first_device};
+    HIP_TRY(hipSetDevice(first_device));
+    for (hipEvent_t& e : ev) HIP_TRY(hipEventCreate(&e));
+    MultiState& m0 = scenes[0]->multi;
     // with ACCUMULATE the first device's frame starts from the caller's sums (tiles: every device's frame does, see the workers)
-    MULTI_TRY(hipEventRecord(copy_in[0], w[0].stream));
-    if (accumulate) MULTI_TRY(hipMemcpyAsync(w[0].d_img, rgb_sum, bytes, hipMemcpyHostToDevice, w[0].stream));
-    MULTI_TRY(hipEventRecord(copy_in[1], w[0].stream));
+    HIP_TRY(hipEventRecord(ev[0], m0.stream));
+    if (accumulate) HIP_TRY(hipMemcpyAsync(m0.d_img, rgb_sum, bytes, hipMemcpyHostToDevice, m0.stream));
+    HIP_TRY(hipEventRecord(ev[1], m0.stream));
 
     // one host thread per handle (main.rs:138-147)
     auto work = [&](uint32_t i) {
         MultiWorker& k = w[i];
+        MultiState& m = k.scene->multi;
         auto fail = [&](hipError_t e, const char* what) {
             k.rc = RRT_ERR_DEVICE;
             k.error = std::string(what) + ": " + hipGetErrorString(e);
         };
         hipError_t e = hipSetDevice(k.scene->device);
         if (e != hipSuccess) return fail(e, "hipSetDevice");
-        if ((e = hipMemsetAsync(k.d_cnt, 0, 16, k.stream)) != hipSuccess) return fail(e, "hipMemsetAsync");
-        if (i > 0 && shard_mode == RRT_SHARD_TILES && accumulate &&
-            (e = hipMemcpyAsync(k.d_img, rgb_sum, bytes, hipMemcpyHostToDevice, k.stream)) != hipSuccess)
+        if ((e = hipMemsetAsync(m.d_cnt, 0, 16, m.stream)) != hipSuccess) return fail(e, "hipMemsetAsync");
+        if (i > 0 && tiles && accumulate && (e = hipMemcpyAsync(m.d_img, rgb_sum, bytes, hipMemcpyHostToDevice, m.stream)) != hipSuccess)
             return fail(e, "hipMemcpyAsync");
-        if ((e = hipEventRecord(k.begin, k.stream)) != hipSuccess) return fail(e, "hipEventRecord");
+        if ((e = hipEventRecord(m.begin, m.stream)) != hipSuccess) return fail(e, "hipEventRecord");
         k.mark = k.scene->events_used;
         k.scene->timing = true;
         if (k.params.samples != 0) {
-            k.rc = render_passes(k.scene, &k.params, k.d_img, k.d_cnt, k.stream, false);
+            k.rc = render_passes(k.scene, &k.params, m.d_img, m.d_cnt, m.stream, false);
             if (k.rc) {
                 k.error = rrt_last_error();
                 return;
             }
-        } else if (!(accumulate && (i == 0 || shard_mode == RRT_SHARD_TILES))) {
-            if ((e = hipMemsetAsync(k.d_img, 0, bytes, k.stream)) != hipSuccess) return fail(e, "hipMemsetAsync");  // nothing to trace: a frame of zeros
+        } else if (!(accumulate && (i == 0 || tiles))) {
+            if ((e = hipMemsetAsync(m.d_img, 0, bytes, m.stream)) != hipSuccess) return fail(e, "hipMemsetAsync");  // nothing to trace: a frame of zeros
         }
-        if ((e = hipEventRecord(k.end, k.stream)) != hipSuccess) return fail(e, "hipEventRecord");
-        if ((e = hipEventSynchronize(k.end)) != hipSuccess) return fail(e, "hipEventSynchronize");
+        if ((e = hipEventRecord(m.end, m.stream)) != hipSuccess) return fail(e, "hipEventRecord");
+        if (i > 0) {
+            // the push follows the render on the same stream: it starts the moment THIS device is done, whatever the others do
+            const size_t floats = push_floats(i);
+            const float* from = m.d_img;
+            if (tiles) {
+                if (floats) hipLaunchKernelGGL(k_pack_tiles, dim3((unsigned)((floats + 255) / 256)), dim3(256), 0, m.stream, m.d_img, m.d_pack, floats, W, H, tiles_x, n_tiles, n, i);
+                if ((e = hipGetLastError()) != hipSuccess) return fail(e, "k_pack_tiles");
+                from = m.d_pack;
+            }
+            if (floats && (e = hipMemcpyPeerAsync(m.landing, first_device, from, k.scene->device, floats * sizeof(float), m.stream)) != hipSuccess)
+                return fail(e, "hipMemcpyPeerAsync");
+            if ((e = hipEventRecord(m.landed, m.stream)) != hipSuccess) return fail(e, "hipEventRecord");
+        }
+        if ((e = hipEventSynchronize(m.end)) != hipSuccess) return fail(e, "hipEventSynchronize");
         float ms = 0.0f;
-        if ((e = hipEventElapsedTime(&ms, k.begin, k.end)) != hipSuccess) return fail(e, "hipEventElapsedTime");
+        if ((e = hipEventElapsedTime(&ms, m.begin, m.end)) != hipSuccess) return fail(e, "hipEventElapsedTime");
         k.render_s = (double)ms * 1e-3;
         k.rc = passes_since(k.scene, k.mark, k.user_timing, &k.trace_s, &k.accumulate_s);
         if (k.rc) k.error = rrt_last_error();
-        if ((e = hipMemcpy(k.counters, k.d_cnt, 16, hipMemcpyDeviceToHost)) != hipSuccess) return fail(e, "hipMemcpy");
+        if ((e = hipMemcpyAsync(k.counters, m.d_cnt, 16, hipMemcpyDeviceToHost, m.stream)) != hipSuccess) return fail(e, "hipMemcpyAsync");
+        if ((e = hipStreamSynchronize(m.stream)) != hipSuccess) return fail(e, "hipStreamSynchronize");
     };
     {
         std::vector<std::thread> pool;
@@ -2053,33 +2159,25 @@ static int render_multi(rrt_scene* const* scenes, uint32_t n, uint32_t shard_mod
         for (std::thread& t : pool) t.join();
     }
     for (const MultiWorker& k : w)
-        if (k.rc) {
-            const int rc = k.rc;
-            const std::string msg = "rrt_render_multi, device " + std::to_string(k.scene->device) + ": " + k.error;
-            release_all();
-            return rrt_set_error(rc, msg);
-        }
-    // gather on the first device: the copies run side by side (one stream, one link each), the adds in device order
-    MULTI_TRY(hipSetDevice(first_device));
-    MULTI_TRY(hipEventRecord(reduce_ev[0], w[0].stream));
+        if (k.rc) return rrt_set_error(k.rc, "rrt_render_multi, device " + std::to_string(k.scene->device) + ": " + k.error);
+    // gather on the first device, in device order
+    HIP_TRY(hipSetDevice(first_device));
+    HIP_TRY(hipEventRecord(ev[2], m0.stream));
     for (uint32_t i = 1; i < n; ++i) {
-        MULTI_TRY(hipStreamWaitEvent(w[i].copy_stream, reduce_ev[0], 0));
-        MULTI_TRY(hipMemcpyPeerAsync(w[i].d_landing, first_device, w[i].d_img, w[i].scene->device, bytes, w[i].copy_stream));
-        MULTI_TRY(hipEventRecord(w[i].landed, w[i].copy_stream));
+        const MultiState& m = scenes[i]->multi;
+        const size_t floats = push_floats(i);
+        HIP_TRY(hipStreamWaitEvent(m0.stream, m.landed, 0));
+        if (!floats) continue;
+        const dim3 grid((unsigned)((floats + 255) / 256));
+        if (tiles) hipLaunchKernelGGL(k_unpack_tiles, grid, dim3(256), 0, m0.stream, m0.d_img, m.landing, floats, W, H, tiles_x, n_tiles, n, i);
+        else hipLaunchKernelGGL(k_add_frame, grid, dim3(256), 0, m0.stream, m0.d_img, m.landing, floats);
+        HIP_TRY(hipGetLastError());
     }
-    for (uint32_t i = 1; i < n; ++i) {
-        MULTI_TRY(hipStreamWaitEvent(w[0].stream, w[i].landed, 0));
-        const dim3 grid((unsigned)((frame_floats + 255) / 256));
-        if (shard_mode == RRT_SHARD_TILES)
-            hipLaunchKernelGGL(k_take_tiles, grid, dim3(256), 0, w[0].stream, w[0].d_img, w[i].d_landing, frame_floats, W, (W + 31) / 32, n, i);
-        else hipLaunchKernelGGL(k_add_frame, grid, dim3(256), 0, w[0].stream, w[0].d_img, w[i].d_landing, frame_floats);
-        MULTI_TRY(hipGetLastError());
-    }
-    MULTI_TRY(hipEventRecord(reduce_ev[1], w[0].stream));
-    MULTI_TRY(hipEventRecord(copy_out[0], w[0].stream));
-    MULTI_TRY(hipMemcpyAsync(rgb_sum, w[0].d_img, bytes, hipMemcpyDeviceToHost, w[0].stream));
-    MULTI_TRY(hipEventRecord(copy_out[1], w[0].stream));
-    MULTI_TRY(hipEventSynchronize(copy_out[1]));
+    HIP_TRY(hipEventRecord(ev[3], m0.stream));
+    HIP_TRY(hipEventRecord(ev[4], m0.stream));
+    HIP_TRY(hipMemcpyAsync(rgb_sum, m0.d_img, bytes, hipMemcpyDeviceToHost, m0.stream));
+    HIP_TRY(hipEventRecord(ev[5], m0.stream));
+    HIP_TRY(hipEventSynchronize(ev[5]));
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         for (const MultiWorker& k : w) {
@@ -2092,14 +2190,12 @@ static int render_multi(rrt_scene* const* scenes, uint32_t n, uint32_t shard_mod
             }
         }
         float ms_in = 0.0f, ms_red = 0.0f, ms_out = 0.0f;
-        MULTI_TRY(hipEventElapsedTime(&ms_in, copy_in[0], copy_in[1]));
-        MULTI_TRY(hipEventElapsedTime(&ms_red, reduce_ev[0], reduce_ev[1]));
-        MULTI_TRY(hipEventElapsedTime(&ms_out, copy_out[0], copy_out[1]));
+        HIP_TRY(hipEventElapsedTime(&ms_in, ev[0], ev[1]));
+        HIP_TRY(hipEventElapsedTime(&ms_red, ev[2], ev[3]));
+        HIP_TRY(hipEventElapsedTime(&ms_out, ev[4], ev[5]));
         stats->reduce_seconds = (double)ms_red * 1e-3;
         stats->copy_seconds = ((double)ms_in + (double)ms_out) * 1e-3;
     }
-#undef MULTI_TRY
-    release_all();
     return RRT_OK;
 }
 

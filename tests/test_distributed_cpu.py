@@ -1,5 +1,5 @@
 """The N > 1 path on CPU: two gloo ranks shard one frame (sample ranges, interleaved tiles) and combine it with
-the single reduce the GPU job uses.  The per-rank renders come from the CPU oracle; what is under test is the sharding
+the single collective the GPU job uses (a sum for sample ranges, a gather of each rank's own pixels for tiles).  The per-rank renders come from the CPU oracle; what is under test is the sharding
 arithmetic and the collective, which are the same code bench.py runs over RCCL."""
 import os
 import socket
@@ -38,9 +38,13 @@ def _worker(rank, world, port, mode, out_dir):
         img, _ = sc.render(W, H, n, first_sample=first, seed=3, threads=2)
     else:
         full, _ = sc.render(W, H, SPP, seed=3, threads=2)
-        img = np.where(shard.tile_owner_mask(W, H, world, rank)[..., None], full, np.float32(0)).astype(np.float32)
+        # (pixels of other ranks' tiles hold stale values, as a tile-sharded GPU render leaves them)
+        img = np.where(shard.tile_owner_mask(W, H, world, rank)[..., None], full, np.float32(77)).astype(np.float32)
     frame = torch.from_numpy(np.nan_to_num(img))
-    shard.reduce_frame(frame, dst=0)
+    if mode == "tiles":
+        shard.gather_tiles(frame, dst=0)
+    else:
+        shard.reduce_frame(frame, dst=0)
     if rank == 0:
         np.save(os.path.join(out_dir, "frame_%s.npy" % mode), frame.numpy())
     dist.barrier()

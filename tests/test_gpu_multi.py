@@ -87,6 +87,28 @@ def test_accumulate_and_argument_checks(gpu):
         rrt.render_multi(gs, shard=5)
 
 
+def test_buffers_kept_between_calls_more_handles_than_tiles_and_mismatched_handles(gpu):
+    """The handles keep their frames, landing buffers, streams and events from call to call: a larger frame after a smaller one (the
+    buffers grow), then a smaller one again (they are reused), each bit-identical to one handle; a frame of ONE tile over three
+    handles (two of them own nothing and push nothing); and handles that hold different scenes are refused."""
+    gs = handles("Cornell_Box_With_Sphere.json", 3, W=48, H=40, spp=5)
+    for W, H, spp, shard in ((48, 40, 5, rrt.SHARD_TILES), (130, 97, 3, rrt.SHARD_TILES), (130, 97, 3, rrt.SHARD_SAMPLES), (33, 20, 4, rrt.SHARD_TILES),
+                             (32, 32, 6, rrt.SHARD_TILES)):
+        img, st = rrt.render_multi(gs, shard=shard, seed=11, width=W, height=H, samples=spp)
+        ref, st_ref = gs[0].render(seed=11, width=W, height=H, samples=spp)
+        assert st["rays"] == st_ref["rays"] and st["paths"] == W * H * spp
+        if shard == rrt.SHARD_TILES:
+            same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+            assert same.all(), "%d values differ at %dx%d" % ((~same).sum(), W, H)
+        else:
+            ok = np.isfinite(ref) & np.isfinite(img)
+            assert np.allclose(img[ok], ref[ok], rtol=1e-5, atol=1e-6)
+    other = handles("Cornell_Box.json", 1, W=48, H=40, spp=5)
+    with pytest.raises(rrt.RrtError) as e:
+        rrt.render_multi([gs[0], other[0]], seed=1)
+    assert "same scene" in e.value.message
+
+
 def test_bench_with_two_ranks_sharing_the_gpu(gpu):
     """bench.py's N > 1 path on real hardware: two ranks under torch.distributed.run on the box's single GPU (they share it and talk
     over gloo - a rehearsal, it measures nothing): render on its own stream, event, collective, resolve, and the strong-scaling
@@ -106,4 +128,4 @@ def test_bench_with_two_ranks_sharing_the_gpu(gpu):
     rec = json.loads(line[0])
     assert rec["n_gpus"] == 2 and rec["scaling"] == "weak" and "rehearsal" in rec["config"]
     assert rec["value"] > 0 and rec["roofline"]["kernel"] == "k_trace_pool"
-    assert set(rec["strong"]) == {"samples", "tiles"} and all(v["value"] > 0 for v in rec["strong"].values())
+    assert set(rec["strong"]) == {"samples", "tiles"} and all(v["value"] > 0 and v["efficiency_vs_1gpu"] > 0 for v in rec["strong"].values())
