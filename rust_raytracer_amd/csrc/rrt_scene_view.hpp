@@ -189,7 +189,10 @@ RRT_DEV float perlin_turbulence(f3 p, uint32_t depth, float omega) {  // utils.r
 }
 
 // ---- textures (texture.rs:61-179) ------------------------------------------------------------------------
-RRT_DEV f3 texture_value(const DScene& sc, int tex, float u, float v, f3 p) {
+// (Not inlined: the shading code asks for a texture's value in seven places - three per bump map, one per material branch - and
+// seven copies of the noise, turbulence, checker and image code made the textured kernel variants larger than the instruction
+// cache.  One copy, called.)
+__device__ __noinline__ f3 texture_value(const DScene& sc, int tex, float u, float v, f3 p) {
     for (;;) {
         const ctexture_p tp = sc.c_textures() + tex;
         struct { uint32_t type; float a, b, c; uint32_t u0, u1, u2, u3; } t = {tp->type, tp->a, tp->b, tp->c, tp->u0, tp->u1, tp->u2, tp->u3};
