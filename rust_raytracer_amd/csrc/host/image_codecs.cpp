@@ -1,5 +1,5 @@
-// JPEG (baseline sequential, 8-bit) and PNG (non-interlaced) decoders for Image textures
-// (texture.rs:121-141 reads texels through image::open, resources.rs:41).
+// JPEG (8-bit Huffman-coded: baseline and multi-scan sequential, progressive) and PNG (plain and Adam7-interlaced) decoders for
+// Image textures (texture.rs:121-141 reads texels through image::open, resources.rs:41).
 //
 // The JPEG path follows the IJG integer pipeline — the "slow but accurate" 8x8 inverse DCT with 13-bit
 // constants and the 16-bit fixed-point YCbCr->RGB tables — so that decoded texels agree with the widely
@@ -136,12 +136,16 @@ void idct_block(const int* coef, const uint16_t* quant, uint8_t* out, int stride
 
 }  // namespace
 
+// Decodes every scan of the file into per-component coefficient arrays - one scan of all components (baseline files), several
+// scans of some components each (multi-scan sequential files), or the spectral-selection / successive-approximation scans of a
+// progressive file - and runs the inverse transform once, at the end of the image.
 std::string decode_jpeg(const std::vector<uint8_t>& f, uint32_t* w, uint32_t* h, uint32_t* channels, std::vector<uint8_t>* px) {
     uint16_t quant[4][64] = {};
     Huff dc[4], ac[4];
     Component comp[4];
-    int ncomp = 0, width = 0, height = 0, restart_interval = 0;
-    bool have_frame = false;
+    std::vector<int16_t> coefs[4];  // [block][64], natural (row-major) order within a block
+    int ncomp = 0, width = 0, height = 0, restart_interval = 0, hmax = 1, vmax = 1, mcux = 0, mcuy = 0;
+    bool have_frame = false, progressive = false, any_scan = false;
     size_t i = 2;
     auto be16 = [&](size_t at) { return (int)((f[at] << 8) | f[at + 1]); };
     while (i + 4 <= f.size()) {
@@ -195,19 +199,21 @@ std::string decode_jpeg(const std::vector<uint8_t>& f, uint32_t* w, uint32_t* h,
                 }
                 t.present = true;
             }
-        } else if (marker == 0xC0 || marker == 0xC1) {  // baseline / extended sequential, Huffman
+        } else if (marker == 0xC0 || marker == 0xC1 || marker == 0xC2) {  // baseline / extended sequential / progressive, Huffman
+            if (have_frame) return "JPEG: more than one frame";
             if (len < 8) return "JPEG: truncated frame header";
             if (f[seg] != 8) return "JPEG: only 8-bit samples are supported";
+            progressive = marker == 0xC2;
             height = be16(seg + 1);
             width = be16(seg + 3);
             ncomp = f[seg + 5];
             if (width <= 0 || height <= 0 || (ncomp != 1 && ncomp != 3)) return "JPEG: unsupported frame";
             if (len < 8 + 3 * ncomp) return "JPEG: truncated frame header";
             if ((uint64_t)width * (uint64_t)height > kMaxImagePixels) return "JPEG: image too large";
-            // An 8x8 block costs at least two bits of entropy-coded data (a one-bit DC code and a one-bit end-of-block), so a
-            // file of n bytes describes at most 256 n pixels: a frame header that claims more is lying, and is refused before
-            // any plane is allocated.
-            if ((uint64_t)width * (uint64_t)height > (uint64_t)f.size() * 256u) return "JPEG: frame larger than the file's data can describe";
+            // An 8x8 block costs at least two bits of entropy-coded data in a sequential file (a one-bit DC code and a one-bit
+            // end-of-block) and one bit in a progressive one (its DC scan), so a file of n bytes describes at most 256 n (512 n)
+            // pixels: a frame header that claims more is lying, and is refused before anything is allocated.
+            if ((uint64_t)width * (uint64_t)height > (uint64_t)f.size() * (progressive ? 512u : 256u)) return "JPEG: frame larger than the file's data can describe";
             for (int c = 0; c < ncomp; ++c) {
                 comp[c].id = f[seg + 6 + 3 * c];
                 comp[c].h = f[seg + 7 + 3 * c] >> 4;
@@ -215,117 +221,217 @@ std::string decode_jpeg(const std::vector<uint8_t>& f, uint32_t* w, uint32_t* h,
                 comp[c].tq = f[seg + 8 + 3 * c];
                 if (comp[c].h < 1 || comp[c].h > 2 || comp[c].v < 1 || comp[c].v > 2 || comp[c].tq > 3) return "JPEG: unsupported sampling";
             }
-            have_frame = true;
-        } else if (marker == 0xC2) {
-            return "JPEG: progressive files are not supported";
-        } else if (marker == 0xDD) {
-            if (len < 4) return "JPEG: truncated restart interval";
-            restart_interval = be16(seg);
-        } else if (marker == 0xDA) {  // start of scan: decode the whole (single, interleaved) scan
-            if (!have_frame) return "JPEG: scan before frame";
-            if (len < 3) return "JPEG: truncated scan header";
-            int ns = f[seg];
-            if (ns != ncomp) return "JPEG: multi-scan files are not supported";
-            if (len < 6 + 2 * ns) return "JPEG: truncated scan header";
-            for (int k = 0; k < ns; ++k) {
-                int cid = f[seg + 1 + 2 * k];
-                for (int c = 0; c < ncomp; ++c)
-                    if (comp[c].id == cid) {
-                        comp[c].td = f[seg + 2 + 2 * k] >> 4;
-                        comp[c].ta = f[seg + 2 + 2 * k] & 15;
-                    }
-            }
-            for (int c = 0; c < ncomp; ++c)
-                if (comp[c].td > 3 || comp[c].ta > 3) return "JPEG: bad Huffman table id in scan";
-            int hmax = 1, vmax = 1;
+            if (ncomp == 1) comp[0].h = comp[0].v = 1;
             for (int c = 0; c < ncomp; ++c) {
                 hmax = comp[c].h > hmax ? comp[c].h : hmax;
                 vmax = comp[c].v > vmax ? comp[c].v : vmax;
             }
-            if (ncomp == 1) comp[0].h = comp[0].v = hmax = vmax = 1;
-            int mcux = (width + 8 * hmax - 1) / (8 * hmax), mcuy = (height + 8 * vmax - 1) / (8 * vmax);
+            mcux = (width + 8 * hmax - 1) / (8 * hmax);
+            mcuy = (height + 8 * vmax - 1) / (8 * vmax);
             for (int c = 0; c < ncomp; ++c) {
                 comp[c].bw = mcux * comp[c].h;
                 comp[c].bh = mcuy * comp[c].v;
-                comp[c].plane.assign((size_t)comp[c].bw * 8 * comp[c].bh * 8, 0);
-                comp[c].pred = 0;
-                if (!dc[comp[c].td].present || !ac[comp[c].ta].present) return "JPEG: missing Huffman table";
+                coefs[c].assign((size_t)comp[c].bw * comp[c].bh * 64, 0);
+            }
+            have_frame = true;
+        } else if (marker == 0xC3 || (marker >= 0xC5 && marker <= 0xCF && marker != 0xC8 && marker != 0xCC)) {
+            return "JPEG: lossless, hierarchical and arithmetic-coded files are not supported";
+        } else if (marker == 0xDD) {
+            if (len < 4) return "JPEG: truncated restart interval";
+            restart_interval = be16(seg);
+        } else if (marker == 0xDA) {  // start of scan
+            if (!have_frame) return "JPEG: scan before frame";
+            if (len < 3) return "JPEG: truncated scan header";
+            const int ns = f[seg];
+            if (ns < 1 || ns > ncomp) return "JPEG: bad number of components in scan";
+            if (len < 6 + 2 * ns) return "JPEG: truncated scan header";
+            int in_scan[4];
+            for (int k = 0; k < ns; ++k) {
+                const int cid = f[seg + 1 + 2 * k];
+                int found = -1;
+                for (int c = 0; c < ncomp; ++c)
+                    if (comp[c].id == cid) found = c;
+                if (found < 0) return "JPEG: scan names a component the frame does not have";
+                for (int q = 0; q < k; ++q)
+                    if (in_scan[q] == found) return "JPEG: a component appears twice in a scan";
+                in_scan[k] = found;
+                comp[found].td = f[seg + 2 + 2 * k] >> 4;
+                comp[found].ta = f[seg + 2 + 2 * k] & 15;
+                if (comp[found].td > 3 || comp[found].ta > 3) return "JPEG: bad Huffman table id in scan";
+            }
+            int Ss = f[seg + 1 + 2 * ns], Se = f[seg + 2 + 2 * ns], Ah = f[seg + 3 + 2 * ns] >> 4, Al = f[seg + 3 + 2 * ns] & 15;
+            if (!progressive) {
+                Ss = 0;
+                Se = 63;
+                Ah = Al = 0;
+            } else {
+                if (Ss > Se || Se > 63 || Ah > 13 || Al > 13) return "JPEG: bad spectral selection or successive approximation";
+                if (Ss == 0 && Se != 0) return "JPEG: a progressive scan mixes DC and AC coefficients";
+                if (Ss != 0 && ns != 1) return "JPEG: a progressive AC scan of several components";
+                if (Ah != 0 && Ah != Al + 1) return "JPEG: bad successive approximation";
+            }
+            const bool needs_dc = Ss == 0 && Ah == 0, needs_ac = Se > 0;
+            for (int k = 0; k < ns; ++k) {
+                const Component& cc = comp[in_scan[k]];
+                if (needs_dc && !dc[cc.td].present) return "JPEG: missing Huffman table";
+                if (needs_ac && !ac[cc.ta].present) return "JPEG: missing Huffman table";
+                comp[in_scan[k]].pred = 0;
+            }
+            // the units the scan walks over: MCUs when it holds several components, otherwise the blocks of the one component
+            // that cover the image (not the padding that rounds the component up to whole MCUs)
+            int ux = mcux, uy = mcuy;
+            if (ns == 1) {
+                const Component& cc = comp[in_scan[0]];
+                ux = ((width * cc.h + hmax - 1) / hmax + 7) / 8;
+                uy = ((height * cc.v + vmax - 1) / vmax + 7) / 8;
             }
             JpegReader rd{f.data() + seg_end, f.data() + f.size()};
-            int mcu_count = 0, next_rst = 0;
-            for (int my = 0; my < mcuy; ++my) {
-                for (int mx = 0; mx < mcux; ++mx) {
-                    if (restart_interval && mcu_count && mcu_count % restart_interval == 0) {
+            int unit_count = 0, eobrun = 0;
+            const int p1 = 1 << Al, m1 = -(1 << Al);
+            for (int my = 0; my < uy; ++my) {
+                for (int mx = 0; mx < ux; ++mx) {
+                    if (restart_interval && unit_count && unit_count % restart_interval == 0) {
                         // byte-align and consume the RSTn marker
                         rd.reset_bits();
                         while (rd.p + 1 < rd.end && !(rd.p[0] == 0xFF && rd.p[1] >= 0xD0 && rd.p[1] <= 0xD7)) ++rd.p;
                         if (rd.p + 1 < rd.end) rd.p += 2;
-                        next_rst = (next_rst + 1) & 7;
-                        for (int c = 0; c < ncomp; ++c) comp[c].pred = 0;
+                        for (int k = 0; k < ns; ++k) comp[in_scan[k]].pred = 0;
+                        eobrun = 0;
                     }
-                    for (int c = 0; c < ncomp; ++c) {
-                        for (int by = 0; by < comp[c].v; ++by) {
-                            for (int bx = 0; bx < comp[c].h; ++bx) {
-                                int coef[64] = {0};
-                                int s = rd.decode(dc[comp[c].td]);
-                                if (s < 0 || s > 15) return "JPEG: bad DC code";
-                                int diff = s ? extend(rd.get_bits(s), s) : 0;
-                                comp[c].pred += diff;
-                                coef[0] = comp[c].pred;
-                                for (int k = 1; k < 64;) {
-                                    int rs = rd.decode(ac[comp[c].ta]);
-                                    if (rs < 0) return "JPEG: bad AC code";
-                                    int r = rs >> 4, sz = rs & 15;
-                                    if (sz == 0) {
-                                        if (r == 15) { k += 16; continue; }
-                                        break;
+                    for (int k = 0; k < ns; ++k) {
+                        Component& cc = comp[in_scan[k]];
+                        const int nbx = ns == 1 ? 1 : cc.h, nby = ns == 1 ? 1 : cc.v;
+                        for (int by = 0; by < nby; ++by) {
+                            for (int bx = 0; bx < nbx; ++bx) {
+                                const int gx = ns == 1 ? mx : mx * cc.h + bx, gy = ns == 1 ? my : my * cc.v + by;
+                                int16_t* blk = &coefs[in_scan[k]][((size_t)gy * cc.bw + gx) * 64];
+                                if (Ss == 0) {
+                                    if (Ah == 0) {  // the DC coefficient (whole, or its high bits)
+                                        int sz = rd.decode(dc[cc.td]);
+                                        if (sz < 0 || sz > 15) return "JPEG: bad DC code";
+                                        int diff = sz ? extend(rd.get_bits(sz), sz) : 0;
+                                        cc.pred += diff;
+                                        blk[0] = (int16_t)(cc.pred * (1 << Al));
+                                    } else if (rd.get_bits(1)) {  // one more bit of it
+                                        blk[0] = (int16_t)(blk[0] | p1);
                                     }
-                                    k += r;
-                                    if (k > 63) return "JPEG: coefficient index out of range";
-                                    coef[kZigzag[k]] = extend(rd.get_bits(sz), sz);
-                                    ++k;
                                 }
-                                int px0 = (mx * comp[c].h + bx) * 8, py0 = (my * comp[c].v + by) * 8;
-                                int stride = comp[c].bw * 8;
-                                idct_block(coef, quant[comp[c].tq], &comp[c].plane[(size_t)py0 * stride + px0], stride);
+                                if (Se == 0) continue;
+                                int kk = Ss == 0 ? 1 : Ss;
+                                if (Ah == 0) {  // AC coefficients Ss..Se (whole, or their high bits)
+                                    if (eobrun > 0) {
+                                        --eobrun;
+                                        continue;
+                                    }
+                                    for (; kk <= Se; ++kk) {
+                                        int rs = rd.decode(ac[cc.ta]);
+                                        if (rs < 0) return "JPEG: bad AC code";
+                                        int r = rs >> 4, sz = rs & 15;
+                                        if (sz) {
+                                            kk += r;
+                                            if (kk > Se) return "JPEG: coefficient index out of range";
+                                            blk[kZigzag[kk]] = (int16_t)(extend(rd.get_bits(sz), sz) * (1 << Al));
+                                        } else if (r == 15) {
+                                            kk += 15;
+                                        } else {
+                                            if (!progressive && r != 0) return "JPEG: bad AC code";
+                                            eobrun = 1 << r;
+                                            if (r) eobrun += rd.get_bits(r);
+                                            --eobrun;
+                                            break;
+                                        }
+                                    }
+                                } else {  // one more bit of the AC coefficients Ss..Se
+                                    if (eobrun == 0) {
+                                        for (; kk <= Se; ++kk) {
+                                            int rs = rd.decode(ac[cc.ta]);
+                                            if (rs < 0) return "JPEG: bad AC code";
+                                            int r = rs >> 4, sz = rs & 15, value = 0;
+                                            if (sz) {
+                                                if (sz != 1) return "JPEG: bad AC refinement code";
+                                                value = rd.get_bits(1) ? p1 : m1;
+                                            } else if (r != 15) {
+                                                eobrun = 1 << r;
+                                                if (r) eobrun += rd.get_bits(r);
+                                                break;  // the rest of the band is handled below
+                                            }
+                                            // pass the coefficients that are already non-zero (each takes a correction bit) and r that are still zero
+                                            for (; kk <= Se; ++kk) {
+                                                int16_t& cf = blk[kZigzag[kk]];
+                                                if (cf != 0) {
+                                                    if (rd.get_bits(1) && (cf & p1) == 0) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+                                                } else if (--r < 0) break;
+                                            }
+                                            if (value) {
+                                                if (kk > Se) return "JPEG: coefficient index out of range";
+                                                blk[kZigzag[kk]] = (int16_t)value;
+                                            }
+                                        }
+                                    }
+                                    if (eobrun > 0) {  // to the end of the band: correction bits for what is already non-zero
+                                        for (; kk <= Se; ++kk) {
+                                            int16_t& cf = blk[kZigzag[kk]];
+                                            if (cf != 0 && rd.get_bits(1) && (cf & p1) == 0) cf = (int16_t)(cf + (cf >= 0 ? p1 : m1));
+                                        }
+                                        --eobrun;
+                                    }
+                                }
                             }
                         }
                     }
-                    ++mcu_count;
+                    ++unit_count;
                 }
             }
-            // assemble
-            *w = (uint32_t)width;
-            *h = (uint32_t)height;
-            *channels = ncomp == 1 ? 1u : 3u;
-            px->resize((size_t)width * height * *channels);
-            if (ncomp == 1) {
-                int stride = comp[0].bw * 8;
-                for (int y = 0; y < height; ++y) std::memcpy(&(*px)[(size_t)y * width], &comp[0].plane[(size_t)y * stride], (size_t)width);
-            } else {
-                for (int y = 0; y < height; ++y) {
-                    for (int x = 0; x < width; ++x) {
-                        int s[3];
-                        for (int c = 0; c < 3; ++c) {
-                            int sx = x * comp[c].h / hmax, sy = y * comp[c].v / vmax;
-                            s[c] = comp[c].plane[(size_t)sy * comp[c].bw * 8 + sx];
-                        }
-                        int Y = s[0], cb = s[1] - 128, cr = s[2] - 128;
-                        int r = Y + (int)((91881L * cr + 32768) >> 16);
-                        int g = Y + (int)((-22554L * cb + 32768 + -46802L * cr) >> 16);
-                        int b = Y + (int)((116130L * cb + 32768) >> 16);
-                        uint8_t* q = &(*px)[((size_t)y * width + x) * 3];
-                        q[0] = clamp8(r);
-                        q[1] = clamp8(g);
-                        q[2] = clamp8(b);
-                    }
-                }
-            }
-            return "";
+            any_scan = true;
+            // the entropy-coded data runs up to the next marker that is not a restart marker or a stuffed byte
+            size_t at = (size_t)(rd.p - f.data());
+            if (rd.hit_marker) at = (size_t)(rd.p - f.data());
+            while (at + 1 < f.size() && !(f[at] == 0xFF && f[at + 1] != 0x00 && !(f[at + 1] >= 0xD0 && f[at + 1] <= 0xD7) && f[at + 1] != 0xFF)) ++at;
+            i = at;
+            continue;
         }
         i = seg_end;
     }
-    return "JPEG: no image data found";
+    if (!have_frame || !any_scan) return "JPEG: no image data found";
+    // inverse transform and assembly
+    for (int c = 0; c < ncomp; ++c) {
+        comp[c].plane.assign((size_t)comp[c].bw * 8 * comp[c].bh * 8, 0);
+        const int stride = comp[c].bw * 8;
+        for (int gy = 0; gy < comp[c].bh; ++gy)
+            for (int gx = 0; gx < comp[c].bw; ++gx) {
+                int coef[64];
+                const int16_t* blk = &coefs[c][((size_t)gy * comp[c].bw + gx) * 64];
+                for (int k = 0; k < 64; ++k) coef[k] = blk[k];
+                idct_block(coef, quant[comp[c].tq], &comp[c].plane[(size_t)gy * 8 * stride + (size_t)gx * 8], stride);
+            }
+    }
+    *w = (uint32_t)width;
+    *h = (uint32_t)height;
+    *channels = ncomp == 1 ? 1u : 3u;
+    px->resize((size_t)width * height * *channels);
+    if (ncomp == 1) {
+        int stride = comp[0].bw * 8;
+        for (int y = 0; y < height; ++y) std::memcpy(&(*px)[(size_t)y * width], &comp[0].plane[(size_t)y * stride], (size_t)width);
+    } else {
+        for (int y = 0; y < height; ++y) {
+            for (int x = 0; x < width; ++x) {
+                int sv[3];
+                for (int c = 0; c < 3; ++c) {
+                    int sx = x * comp[c].h / hmax, sy = y * comp[c].v / vmax;
+                    sv[c] = comp[c].plane[(size_t)sy * comp[c].bw * 8 + sx];
+                }
+                int Y = sv[0], cb = sv[1] - 128, cr = sv[2] - 128;
+                int r = Y + (int)((91881L * cr + 32768) >> 16);
+                int g = Y + (int)((-22554L * cb + 32768 + -46802L * cr) >> 16);
+                int b = Y + (int)((116130L * cb + 32768) >> 16);
+                uint8_t* q = &(*px)[((size_t)y * width + x) * 3];
+                q[0] = clamp8(r);
+                q[1] = clamp8(g);
+                q[2] = clamp8(b);
+            }
+        }
+    }
+    return "";
 }
 
 std::string decode_png(const std::vector<uint8_t>& f, uint32_t* w, uint32_t* h, uint32_t* channels, std::vector<uint8_t>* px) {
@@ -357,66 +463,93 @@ std::string decode_png(const std::vector<uint8_t>& f, uint32_t* w, uint32_t* h, 
     }
     if (width == 0 || height == 0) return "PNG: missing IHDR";
     if ((uint64_t)width * (uint64_t)height > kMaxImagePixels) return "PNG: image too large";
-    if (interlace) return "PNG: interlaced files are not supported";
+    if (interlace > 1) return "PNG: unknown interlace method";
     int samples = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 3 ? 1 : ctype == 4 ? 2 : ctype == 6 ? 4 : 0;
     if (!samples || (depth != 8 && depth != 16 && !((ctype == 0 || ctype == 3) && (depth == 1 || depth == 2 || depth == 4))))
         return "PNG: unsupported colour type / bit depth";
-    size_t bpp_bits = (size_t)samples * depth;
-    size_t row_bytes = ((size_t)width * bpp_bits + 7) / 8;
-    size_t bpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;
+    const size_t bpp_bits = (size_t)samples * depth;
+    const size_t bpp = bpp_bits >= 8 ? bpp_bits / 8 : 1;
+    // The image is one pass over all pixels, or the seven passes of Adam7 (each a smaller image of every xstep-th pixel of every
+    // ystep-th row, with filter bytes and a "previous row" of its own).
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass kAdam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    static const Pass kWhole[1] = {{0, 0, 1, 1}};
+    const Pass* passes = interlace ? kAdam7 : kWhole;
+    const int n_passes = interlace ? 7 : 1;
+    auto pass_size = [&](const Pass& ps, uint32_t* pw, uint32_t* ph) {
+        *pw = width > ps.x0 ? (width - ps.x0 + ps.dx - 1) / ps.dx : 0;
+        *ph = height > ps.y0 ? (height - ps.y0 + ps.dy - 1) / ps.dy : 0;
+    };
+    uint64_t raw_bytes = 0;
+    for (int k = 0; k < n_passes; ++k) {
+        uint32_t pw, ph;
+        pass_size(passes[k], &pw, &ph);
+        if (pw && ph) raw_bytes += (uint64_t)(((size_t)pw * bpp_bits + 7) / 8 + 1) * ph;
+    }
     // deflate expands by at most a factor of 1032, so the header's size can be checked against the data before allocating
-    if ((uint64_t)(row_bytes + 1) * height > (uint64_t)idat.size() * 1032u + 1024u) return "PNG: image larger than its data can describe";
-    std::vector<uint8_t> raw((row_bytes + 1) * height);
+    if (raw_bytes > (uint64_t)idat.size() * 1032u + 1024u) return "PNG: image larger than its data can describe";
+    std::vector<uint8_t> raw((size_t)raw_bytes);
     uLongf raw_len = (uLongf)raw.size();
     if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return "PNG: inflate failed";
-    std::vector<uint8_t> prev(row_bytes, 0), cur(row_bytes);
     *w = width;
     *h = height;
     *channels = (ctype == 0 || ctype == 4) ? 1u : 3u;
     px->assign((size_t)width * height * *channels, 0);
-    for (uint32_t y = 0; y < height; ++y) {
-        const uint8_t* line = &raw[(row_bytes + 1) * y];
-        int filter = line[0];
-        for (size_t k = 0; k < row_bytes; ++k) {
-            int a = k >= bpp ? cur[k - bpp] : 0, b = prev[k], c = k >= bpp ? prev[k - bpp] : 0;
-            int x = line[1 + k];
-            switch (filter) {
-                case 0: break;
-                case 1: x += a; break;
-                case 2: x += b; break;
-                case 3: x += (a + b) >> 1; break;
-                case 4: {
-                    int p = a + b - c, pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
-                    x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                    break;
+    size_t at = 0;
+    for (int k = 0; k < n_passes; ++k) {
+        const Pass& ps = passes[k];
+        uint32_t pw, ph;
+        pass_size(ps, &pw, &ph);
+        if (!pw || !ph) continue;
+        const size_t row_bytes = ((size_t)pw * bpp_bits + 7) / 8;
+        std::vector<uint8_t> prev(row_bytes, 0), cur(row_bytes);
+        for (uint32_t py = 0; py < ph; ++py) {
+            const uint8_t* line = &raw[at];
+            at += row_bytes + 1;
+            int filter = line[0];
+            for (size_t j = 0; j < row_bytes; ++j) {
+                int a = j >= bpp ? cur[j - bpp] : 0, b = prev[j], c = j >= bpp ? prev[j - bpp] : 0;
+                int x = line[1 + j];
+                switch (filter) {
+                    case 0: break;
+                    case 1: x += a; break;
+                    case 2: x += b; break;
+                    case 3: x += (a + b) >> 1; break;
+                    case 4: {
+                        int p = a + b - c, pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
+                        x += (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                        break;
+                    }
+                    default: return "PNG: bad filter";
                 }
-                default: return "PNG: bad filter";
+                cur[j] = (uint8_t)x;
             }
-            cur[k] = (uint8_t)x;
-        }
-        for (uint32_t x = 0; x < width; ++x) {
-            uint8_t s[4] = {0, 0, 0, 0};
-            for (int c = 0; c < samples; ++c) {
-                if (depth == 8) s[c] = cur[(size_t)x * samples + c];
-                else if (depth == 16) s[c] = cur[((size_t)x * samples + c) * 2];
-                else {
-                    size_t bit = (size_t)x * depth;
-                    int v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
-                    s[c] = ctype == 3 ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1));
+            const uint32_t y = ps.y0 + py * ps.dy;
+            for (uint32_t qx = 0; qx < pw; ++qx) {
+                const uint32_t x = ps.x0 + qx * ps.dx;
+                uint8_t sv[4] = {0, 0, 0, 0};
+                for (int c = 0; c < samples; ++c) {
+                    if (depth == 8) sv[c] = cur[(size_t)qx * samples + c];
+                    else if (depth == 16) sv[c] = cur[((size_t)qx * samples + c) * 2];
+                    else {
+                        size_t bit = (size_t)qx * depth;
+                        int v = (cur[bit >> 3] >> (8 - depth - (bit & 7))) & ((1 << depth) - 1);
+                        sv[c] = ctype == 3 ? (uint8_t)v : (uint8_t)(v * 255 / ((1 << depth) - 1));
+                    }
+                }
+                uint8_t* q = &(*px)[((size_t)y * width + x) * *channels];
+                if (ctype == 3) {
+                    size_t pi = (size_t)sv[0] * 3;
+                    if (pi + 3 > palette.size()) return "PNG: palette index out of range";
+                    q[0] = palette[pi]; q[1] = palette[pi + 1]; q[2] = palette[pi + 2];
+                } else if (*channels == 1) {
+                    q[0] = sv[0];
+                } else {
+                    q[0] = sv[0]; q[1] = sv[1]; q[2] = sv[2];
                 }
             }
-            uint8_t* q = &(*px)[((size_t)y * width + x) * *channels];
-            if (ctype == 3) {
-                size_t pi = (size_t)s[0] * 3;
-                if (pi + 3 > palette.size()) return "PNG: palette index out of range";
-                q[0] = palette[pi]; q[1] = palette[pi + 1]; q[2] = palette[pi + 2];
-            } else if (*channels == 1) {
-                q[0] = s[0];
-            } else {
-                q[0] = s[0]; q[1] = s[1]; q[2] = s[2];
-            }
+            prev.swap(cur);
         }
-        prev.swap(cur);
     }
     return "";
 }

@@ -85,6 +85,144 @@ def test_jpeg_decoder_matches_pil_for_the_shipped_textures():
         assert got.shape == ref.shape and np.array_equal(got, ref)
 
 
+def _texels_of(tmp_path, names):
+    """Decodes the image files through the scene loader (one Image texture each) and returns their texel arrays."""
+    scene = {"Logistics": {"resolution_x": 8, "resolution_y": 8, "samples": 1},
+             "Camera": {"position": [0, 0, 1], "look_at": [0, 0, 0], "up": [0, 1, 0], "fov": 90, "aspect_ratio": 1, "aperture": 0, "focus_distance": 1},
+             "Textures": {"T%04d" % i: {"type": "Image", "image_path": n} for i, n in enumerate(names)},
+             "Materials": {"M": {"type": "Lambert", "albedo": "T0000"}}, "Aggregate": "BVH",
+             "Shapes": [{"type": "Sphere", "radius": 0.5, "material": "M"}]}
+    (tmp_path / "images.json").write_text(json.dumps(scene))
+    hs = rrt.HostScene.load(str(tmp_path / "images.json"))
+    tex, px = hs.textures(), hs.texels()
+    return [px[t["u3"]: t["u3"] + int(t["u0"]) * int(t["u1"]) * int(t["u2"])].reshape(t["u1"], t["u0"], t["u2"]) for t in tex]
+
+
+def test_progressive_and_multi_scan_jpeg_match_pil(tmp_path):
+    """image::open (resources.rs:41) takes progressive JPEGs as well as baseline ones.  The shipped textures and random images, saved
+    by PIL as progressive files (spectral selection and successive approximation in ten scans, with and without optimised tables,
+    with restart intervals, greyscale and 4:4:4 colour, sizes that are no multiple of the block size), must decode to what PIL decodes."""
+    from PIL import Image
+
+    rng = np.random.default_rng(1)
+    earth = Image.open(orc.asset("earthmap1k.jpg")).convert("RGB")
+    bump = Image.open(orc.asset("earthbump1k.jpg")).convert("L")
+    smooth = np.clip(np.add.outer(np.arange(61) * 3.0, np.arange(83) * 2.0)[..., None] + rng.normal(0, 20, (61, 83, 3)), 0, 255).astype(np.uint8)
+    cases = [("earth_p.jpg", earth, dict(progressive=True, quality=90, subsampling=0)),
+             ("earth_po.jpg", earth.resize((333, 167)), dict(progressive=True, optimize=True, quality=75, subsampling=0)),
+             ("bump_p.jpg", bump, dict(progressive=True, quality=85)),
+             ("bump_small_p.jpg", bump.resize((37, 19)), dict(progressive=True, quality=95)),
+             ("smooth_p.jpg", Image.fromarray(smooth), dict(progressive=True, quality=60, subsampling=0)),
+             ("noise_p.jpg", Image.fromarray(rng.integers(0, 256, (45, 70, 3), dtype=np.uint8)), dict(progressive=True, quality=98, subsampling=0)),
+             ("noise_b.jpg", Image.fromarray(rng.integers(0, 256, (45, 70, 3), dtype=np.uint8)), dict(quality=98, subsampling=0, optimize=True)),
+             ("one_p.jpg", Image.fromarray(rng.integers(0, 256, (1, 1, 3), dtype=np.uint8)), dict(progressive=True, subsampling=0))]
+    for name, img, kw in cases:
+        img.save(tmp_path / name, **kw)
+    # restart intervals inside progressive scans (PIL writes them when asked for)
+    earth.resize((200, 100)).save(tmp_path / "earth_pr.jpg", progressive=True, quality=80, subsampling=0, restart_marker_blocks=7)
+    names = [c[0] for c in cases] + ["earth_pr.jpg"]
+    raw = (tmp_path / "earth_p.jpg").read_bytes()
+    assert b"\xff\xc2" in raw and raw.count(b"\xff\xda") >= 6  # a progressive frame and its many scans
+    for name, got in zip(names, _texels_of(tmp_path, names)):
+        ref = sceneio.load_image(str(tmp_path / name))
+        assert got.shape == ref.shape, name
+        assert np.array_equal(got, ref), "%s: %d texels differ" % (name, int((got != ref).sum()))
+
+
+def _write_png(path, pixels, depth, ctype, interlace, palette=None):
+    """A PNG file of `pixels` ([H, W] or [H, W, samples], integers of `depth` bits), all filter types in turn, Adam7 if asked for."""
+    import struct
+    import zlib
+
+    a = np.asarray(pixels)
+    if a.ndim == 2:
+        a = a[:, :, None]
+    H, W, S = a.shape
+
+    def rows_of(sub):
+        out = bytearray()
+        h, w, _ = sub.shape
+        bpp = max(1, S * depth // 8)
+        prev = np.zeros(((w * S * depth + 7) // 8,), dtype=np.uint8)
+        for y in range(h):
+            if depth == 16:
+                line = sub[y].astype(">u2").tobytes()
+            elif depth == 8:
+                line = sub[y].astype(np.uint8).tobytes()
+            else:
+                bits = np.unpackbits(sub[y].astype(np.uint8).reshape(-1, 1), axis=1)[:, 8 - depth:].reshape(-1)
+                line = np.packbits(bits).tobytes()
+            cur = np.frombuffer(line, dtype=np.uint8).astype(np.int32)
+            f = (y + w) % 5
+            left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            up = prev.astype(np.int32)
+            upleft = np.concatenate([np.zeros(bpp, np.int32), up[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            if f == 0:
+                enc = cur
+            elif f == 1:
+                enc = cur - left
+            elif f == 2:
+                enc = cur - up
+            elif f == 3:
+                enc = cur - ((left + up) >> 1)
+            else:
+                p = left + up - upleft
+                pa, pb, pc = np.abs(p - left), np.abs(p - up), np.abs(p - upleft)
+                enc = cur - np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, up, upleft))
+            out += bytes([f]) + (enc & 255).astype(np.uint8).tobytes()
+            prev = cur.astype(np.uint8)
+        return bytes(out)
+
+    if interlace:
+        data = b""
+        for x0, y0, dx, dy in ((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2)):
+            sub = a[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                data += rows_of(sub)
+    else:
+        data = rows_of(a)
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xffffffff)
+
+    z = zlib.compress(data, 6)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", W, H, depth, ctype, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, dtype=np.uint8).tobytes())
+    out += chunk(b"IDAT", z[: len(z) // 2]) + chunk(b"IDAT", z[len(z) // 2:]) + chunk(b"IEND", b"")
+    with open(path, "wb") as f:
+        f.write(out)
+
+
+def test_interlaced_png_matches_pil(tmp_path):
+    """image::open takes Adam7-interlaced PNGs.  Files written here pass by pass (every filter type, two IDAT chunks; widths and
+    heights from 1 to 19 so that passes come out empty, one pixel wide or ragged; 1- to 16-bit samples, grey, RGB, RGBA, grey with
+    alpha, palette) must decode to the pixels they were made from - as the same pixels stored without interlacing do - and to what PIL decodes."""
+    rng = np.random.default_rng(2)
+    names, expect = [], []
+    for k, (W, H) in enumerate(((1, 1), (2, 3), (5, 4), (8, 8), (9, 17), (19, 7), (16, 16), (3, 1), (1, 9))):
+        for depth, ctype, S in ((8, 2, 3), (8, 0, 1), (8, 6, 4), (16, 2, 3), (4, 0, 1), (1, 0, 1), (8, 4, 2), (2, 3, 1)):
+            px = rng.integers(0, 1 << depth, (H, W, S))
+            pal = rng.integers(0, 256, (4, 3)) if ctype == 3 else None
+            # what the texels must be: 8 bits per sample (the high byte of 16, smaller depths scaled up), alpha dropped
+            if ctype == 3:
+                want = pal[px[:, :, 0]]
+            else:
+                want = px >> 8 if depth == 16 else (px if depth == 8 else px * 255 // ((1 << depth) - 1))
+                want = want[:, :, :3] if ctype in (2, 6) else want[:, :, :1]
+            for interlace in (1, 0):
+                name = "p%d_%d_%d_%d.png" % (k, depth, ctype, interlace)
+                _write_png(tmp_path / name, px, depth, ctype, interlace, pal)
+                names.append(name)
+                expect.append(want.astype(np.uint8))
+    got = _texels_of(tmp_path, names)
+    for name, g, want in zip(names, got, expect):
+        assert g.shape == want.shape, name
+        assert np.array_equal(g, want), "%s: %d texels differ" % (name, int((g != want).sum()))
+        if "_8_2_" in name or "_8_0_" in name or "_8_6_" in name:  # and PIL reads the same from the file
+            assert np.array_equal(g, sceneio.load_image(str(tmp_path / name))), name
+
+
 def test_png_and_pnm_textures(tmp_path):
     from PIL import Image
 
@@ -326,8 +464,14 @@ def test_image_decoders_survive_hostile_files_under_asan(tmp_path):
                            "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "fuzz_image_decoders.cpp"),
                            os.path.join(ROOT, "rust_raytracer_amd", "csrc", "host", "image_codecs.cpp"), "-lz", "-o", exe])
     env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=0")
-    r = subprocess.run([exe] + [str(tmp_path / n) for n in ("sub.jpg", "c444.jpg", "grey.jpg", "a.png")], env=env, capture_output=True, text=True,
-                       timeout=300)
+    Image.fromarray(rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)).save(tmp_path / "prog.jpg", quality=85, subsampling=0, progressive=True)
+    smooth = np.clip(np.add.outer(np.arange(33) * 5.0, np.arange(47) * 3.0) + rng.normal(0, 12, (33, 47)), 0, 255).astype(np.uint8)
+    Image.fromarray(smooth).save(tmp_path / "prog_grey.jpg", quality=70, progressive=True, optimize=True)
+    Image.fromarray(rng.integers(0, 256, (40, 56, 3), dtype=np.uint8)).save(tmp_path / "prog_sub.jpg", quality=80, subsampling=2, progressive=True)
+    _write_png(tmp_path / "adam7.png", rng.integers(0, 256, (21, 19, 3)), 8, 2, 1)
+    _write_png(tmp_path / "adam7_bits.png", rng.integers(0, 4, (9, 13, 1)), 2, 0, 1)
+    files = ("sub.jpg", "c444.jpg", "grey.jpg", "a.png", "prog.jpg", "prog_grey.jpg", "prog_sub.jpg", "adam7.png", "adam7_bits.png")
+    r = subprocess.run([exe] + [str(tmp_path / n) for n in files], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     assert "fuzz ok" in r.stdout
 
