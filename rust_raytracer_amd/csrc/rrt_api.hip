@@ -1364,7 +1364,17 @@ static int scene_create(const rrt_scene_desc* desc, rrt_scene** out) {
     }
     UP(slots, (const float4*)desc->slots, (size_t)desc->n_slots * 3);
     UP(tri_shade, (const float4*)desc->tri_shade, (size_t)desc->n_slots * 4);
-    UP(spheres, desc->spheres, desc->n_spheres);
+    {
+        // (the device copy marks spheres whose world_to_local matrix only translates: see sphere_hit)
+        std::vector<rrt_sphere> sp(desc->spheres, desc->spheres + desc->n_spheres);
+        for (rrt_sphere& q : sp) {
+            const float* m = q.w2l;
+            const bool only = m[0] == 1.0f && m[1] == 0.0f && m[2] == 0.0f && m[4] == 0.0f && m[5] == 1.0f && m[6] == 0.0f && m[8] == 0.0f && m[9] == 0.0f &&
+                              m[10] == 1.0f && std::isfinite(m[3]) && std::isfinite(m[7]) && std::isfinite(m[11]);
+            q.pad[0] = only ? kSphereTranslationOnly : 0u;
+        }
+        UP(spheres, sp.data(), sp.size());
+    }
     UP(media, desc->media, desc->n_media);
     UP(btris, (const float4*)desc->boundary_tris, (size_t)desc->n_boundary_tris * 3);
     UP(btri_shade, (const float4*)desc->boundary_tri_shade, (size_t)desc->n_boundary_tris * 4);

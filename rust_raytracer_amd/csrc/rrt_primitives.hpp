@@ -127,7 +127,36 @@ RRT_DEV bool sphere_hit_m(P w2l, float radius, const Ray& r, float t_min, float 
     }
     return false;
 }
+// The library's own copy of a sphere record marks in pad[0] a world_to_local matrix that only translates (rows (1 0 0 x), (0 1 0 y),
+// (0 0 1 z): every sphere of the reference's scene files but the rotated globe).  For such a sphere the hit distance needs no
+// matrix product: the product's terms are then ray components times one (exact), times zero (a zero, for a finite ray) and the
+// translation, so the local origin is origin + translation and the local direction the direction itself up to the SIGN of a zero
+// component - and a zero's sign cannot reach the distance: every use of the local ray in Sphere::hit (shape.rs:65-85) is a sum of
+// products in which a zero term changes nothing, or -b with b zero next to a positive square root.  (The hit properties, which a
+// zero's sign could reach, keep the full product.)  A ray with an infinite component yields no hit either way.
+constexpr uint32_t kSphereTranslationOnly = 1u;
 RRT_DEV bool sphere_hit(csphere_p s, const Ray& r, float t_min, float t_max, float* t_out) {
+    if (s->pad[0] & kSphereTranslationOnly) {
+        const cf1p m = (cf1p)s->w2l;
+        Ray lr;
+        lr.o = mk3(r.o.x + m[3], r.o.y + m[7], r.o.z + m[11]);
+        lr.d = r.d;
+        const float radius = s->radius;
+        f3 oc = lr.o;
+        float a = dot3(lr.d, lr.d);
+        float b = 2.0f * dot3(oc, lr.d);
+        float c = dot3(oc, oc) - (radius * radius);
+        float disc = b * b - 4.0f * a * c;
+        if (disc > 0.0f) {
+            float t_hit = (-b - __builtin_sqrtf(disc)) / (2.0f * a);
+            if (t_hit >= t_max || t_hit <= t_min) t_hit = (-b + __builtin_sqrtf(disc)) / (2.0f * a);
+            if (t_hit < t_max && t_hit > t_min) {
+                *t_out = t_hit;
+                return true;
+            }
+        }
+        return false;
+    }
     return sphere_hit_m((cf1p)s->w2l, s->radius, r, t_min, t_max, t_out);
 }
 // The boundary shape of a medium that is a sphere or a single triangle.
