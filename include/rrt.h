@@ -294,6 +294,16 @@ void rrt_host_scene_destroy(rrt_host_scene*);
 /* Uploads the flattened scene to the current device's HBM.  ≙ moving Scene into Arc (main.rs:85-95). */
 int rrt_scene_create(const rrt_scene_desc* desc, rrt_scene** out);
 void rrt_scene_destroy(rrt_scene*);
+/* The CPU half of rrt_scene_create alone: no device is touched and nothing is uploaded.  Runs the same checks of the description
+ * (every index a kernel would follow, the links forming one tree, the limits) with the same error codes and messages, prepares the
+ * same device records, and reports what would be uploaded.  layout (may be NULL) receives 8 values: node records (64 bytes each),
+ * pair records (128 bytes each), plain shading records (32 bytes each; 0 unless every texture is Constant and the scene has neither
+ * bump maps nor media), 16-byte entries of the grazing guard's table (0 for trees of more than 16 nodes and clean trees),
+ * traversal stack entries per ray, the feature bits of the kernel variant the scene needs (1 spheres, 2 media, 4 textures other
+ * than Constant, 8 bump maps, 16 media bounded by media), flags (1: single leaf whose lights are its own primitives, 2: the
+ * deep-tree kernels, 4: clean tree), and a hash of the description (what rrt_render_multi compares between its handles).
+ * No counterpart in the reference, whose Scene is valid by construction (scene.rs:130-159). */
+int rrt_scene_check(const rrt_scene_desc* desc, uint64_t* layout);
 /* Host wall-clock seconds rrt_scene_create took (pairing the leaves' triangles, primitive boxes, the copies to HBM). */
 int rrt_scene_upload_seconds(const rrt_scene*, double* seconds);
 /* The parts of that time, in seconds (any pointer may be NULL): the first call that needs the device (a process that has not used

@@ -277,6 +277,8 @@ extern "C" {
     pub fn rrt_scene_create(desc: *const rrt_scene_desc, out: *mut *mut rrt_scene) -> c_int;
     pub fn rrt_scene_create_on(desc: *const rrt_scene_desc, device: c_int, out: *mut *mut rrt_scene) -> c_int;
     pub fn rrt_scene_destroy(s: *mut rrt_scene);
+    /// The CPU half of `rrt_scene_create` alone (checks, device records); `layout`: 8 values or null.
+    pub fn rrt_scene_check(desc: *const rrt_scene_desc, layout: *mut u64) -> c_int;
     pub fn rrt_scene_upload_seconds(s: *const rrt_scene, seconds: *mut f64) -> c_int;
     pub fn rrt_scene_upload_breakdown(s: *const rrt_scene, first_device_call: *mut f64, code_object: *mut f64, host_preparation: *mut f64, copies: *mut f64) -> c_int;
     pub fn rrt_device_count(count: *mut c_int) -> c_int;

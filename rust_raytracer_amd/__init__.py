@@ -138,6 +138,7 @@ def lib():
     L.rrt_scene_create.argtypes = [C.POINTER(_SceneDesc), C.POINTER(vp)]
     L.rrt_scene_destroy.argtypes = [vp]
     L.rrt_scene_create_on.argtypes = [C.POINTER(_SceneDesc), C.c_int, C.POINTER(vp)]
+    L.rrt_scene_check.argtypes = [C.POINTER(_SceneDesc), C.POINTER(C.c_uint64)]
     L.rrt_scene_upload_seconds.argtypes = [vp, C.POINTER(C.c_double)]
     L.rrt_scene_upload_breakdown.argtypes = [vp] + [C.POINTER(C.c_double)] * 4
     L.rrt_device_count.argtypes = [C.POINTER(C.c_int)]
@@ -298,6 +299,14 @@ class HostScene:
         c = self.desc.camera
         return np.array(list(c.origin) + list(c.lower_left_corner) + list(c.horizontal) + list(c.vertical) + list(c.u) + list(c.v)
                         + [c.lens_radius], dtype=np.float32)
+
+    def check(self):
+        """What uploading this scene would put into HBM, worked out on the CPU alone (rrt_scene_check): a dict of record counts, the
+        traversal stack depth, the kernel variant's feature bits and the harvest / deep / clean choices."""
+        v = (C.c_uint64 * 8)()
+        _check(lib().rrt_scene_check(C.byref(self.desc), v))
+        return {"node_records": v[0], "pair_records": v[1], "plain_records": v[2], "guard_entries": v[3], "stack_depth": v[4], "features": v[5],
+                "harvest": bool(v[6] & 1), "deep": bool(v[6] & 2), "clean": bool(v[6] & 4), "desc_hash": v[7]}
 
     def times(self):
         """(load_seconds, build_seconds): reading + decoding the scene file, and building lights / aggregate / flattened arrays."""

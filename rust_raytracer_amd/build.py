@@ -9,15 +9,15 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "librrt_hip.so")
 CLI = os.path.join(HERE, "rust-raytracer")
 
-SOURCES = ["rrt_api.hip", "rrt_stream.hip", "rrt_bvh_build.hip", "rrt_noalloc_area.hip", "rrt_error.cpp", "rrt_abi_layout.cpp", "host/scene_host.cpp", "host/scene_json.cpp", "host/image_io.cpp", "host/image_codecs.cpp"]
-HEADERS = ["cli/main.cpp", "rrt_device.hpp", "rrt_launch.hpp", "rrt_math.hpp", "rrt_scene_view.hpp", "rrt_primitives.hpp", "rrt_profile.hpp", "rrt_traversal.hpp", "rrt_shading.hpp", "rrt_error.hpp", "rrt_bvh_build.hpp", "host/scene_host.hpp", "host/hmath.hpp", "../../include/rrt.h"]
+SOURCES = ["rrt_kernels_shallow.hip", "rrt_scene_prepare.cpp", "rrt_scene.cpp", "rrt_render.cpp", "rrt_multi.cpp", "rrt_stream.hip", "rrt_bvh_build.hip", "rrt_noalloc_area.hip", "rrt_error.cpp", "rrt_abi_layout.cpp", "host/scene_host.cpp", "host/scene_json.cpp", "host/image_io.cpp", "host/image_codecs.cpp"]
+HEADERS = ["cli/main.cpp", "rrt_device.hpp", "rrt_layout.hpp", "rrt_launch.hpp", "rrt_scene_handle.hpp", "rrt_scene_prepare.hpp", "rrt_math.hpp", "rrt_scene_view.hpp", "rrt_primitives.hpp", "rrt_profile.hpp", "rrt_traversal.hpp", "rrt_shading.hpp", "rrt_error.hpp", "rrt_bvh_build.hpp", "host/scene_host.hpp", "host/hmath.hpp", "../../include/rrt.h"]
 
 # -ffp-contract=off: the reference never fuses a*b+c; bit-exact hit decisions need unfused f32 on host and device.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "-Wall", "-Wno-unused-function"]
 # The SLP vectoriser packs scalar f32 arithmetic into two-lane instructions; on gfx950 a packed instruction issues no faster than
 # the two scalar ones and the packing costs register moves: the shallow-tree kernels run 1 - 9 % faster without it, the deep-tree
 # kernels (rrt_stream.hip) 4 % faster with it.  Results are the same bits either way (same IEEE operations, no contraction).
-PER_SOURCE_FLAGS = {"rrt_api.hip": ["-fno-slp-vectorize"]}
+PER_SOURCE_FLAGS = {"rrt_kernels_shallow.hip": ["-fno-slp-vectorize"]}
 
 
 def hipcc():

@@ -134,7 +134,6 @@ RRT_DEV bool sphere_hit_m(P w2l, float radius, const Ray& r, float t_min, float 
 // component - and a zero's sign cannot reach the distance: every use of the local ray in Sphere::hit (shape.rs:65-85) is a sum of
 // products in which a zero term changes nothing, or -b with b zero next to a positive square root.  (The hit properties, which a
 // zero's sign could reach, keep the full product.)  A ray with an infinite component yields no hit either way.
-constexpr uint32_t kSphereTranslationOnly = 1u;
 RRT_DEV bool sphere_hit(csphere_p s, const Ray& r, float t_min, float t_max, float* t_out) {
     if (s->pad[0] & kSphereTranslationOnly) {
         const cf1p m = (cf1p)s->w2l;
@@ -308,16 +307,6 @@ RRT_DEV bool pair_box_overlap_ch(v2f_ hcx, v2f_ hcy, v2f_ hcz, f3 inv, f3 noi, v
     return t_near <= t_far;
 }
 
-// Third traversal mode, chosen by the library for trees built with RRT_AGGREGATE_BVH_CLEAN (never by the caller): nodes are
-// tested with the ordinary interval test on their primitive boxes alone, and equal distances go to the shape that comes
-// first in SCENE order - together exactly what the reference's List aggregate returns (aggregate.rs:142-165).
-constexpr int kAabbClean = 2;
-// Fourth traversal mode (RRT_AABB_EXHAUSTIVE): nodes by the reference's test alone, and EVERY primitive of a visited leaf gets the
-// exact test - no padded box decides anything, so the result is the reference's by construction.  The yardstick the padded-box
-// shortcuts (primitive boxes of nodes, pair boxes of the sifting query) are held against.
-constexpr int kAabbExhaustive = 3;
-constexpr uint32_t kLinkLeaf = 0x80000000u;  // clean trees: a child link that names a leaf's pair records directly
-constexpr uint32_t kLinkNone = 0xffffffffu;  // clean trees: an unused child place of a four-wide node
 
 // box_overlap() that also reports where the span starts (the order in which a four-wide node's children are visited).
 // (The fused form plane * inv + noi of pair_box_overlap() was measured here too: 20 % slower on a 10 M-triangle mesh.)

@@ -9,7 +9,7 @@
 namespace rrt {
 
 #ifdef RRT_PHASE_PROFILE
-// One copy per translation unit of kernels; rrt_profile_read / rrt_profile_read_pool (rrt_api.hip) add the copies up.
+// One copy per translation unit of kernels; rrt_profile_read / rrt_profile_read_pool (rrt_kernels_shallow.hip) add the copies up.
 static __device__ unsigned long long g_prof[8];       // stream kernels: node visits, pair tests, node steps, leaf steps, cycles shade / walk / leaf, shade phases
                                                       // sifting query ([4..7], shallow-tree kernels): filter steps, items, dense groups, phases
 static __device__ unsigned long long g_pool_prof[15]; // k_trace_pool, per kind of work: steps | paths served | cycles

@@ -1,6 +1,7 @@
 // The device view of the uploaded scene, the samplers (utils.rs), Perlin noise and the textures (texture.rs).
 // Each function names the reference code it computes (paths relative to the reference root).
 #pragma once
+#include "rrt_layout.hpp"
 #include "rrt_math.hpp"
 
 namespace rrt {
@@ -22,33 +23,8 @@ RRT_DEV f3 ld3(cf1p p) { return f3{p[0], p[1], p[2]}; }
 RRT_DEV f3 xyz(v4f q) { return f3{q.x, q.y, q.z}; }
 
 // ---- device view of the scene ----------------------------------------------------------------------
-struct DScene {
-    const float4* nodes;      // 4 x float4 per node: the rrt_node (a leaf's `a` holds its first PAIR index), then the padded
-                              // box its primitives occupy (lo, hi), which the TIGHT traversal tests as well: one 64-byte line.
-                              // Clean trees: inner nodes only, four-wide, 4 x float4 (64 bytes) each: the origin and the power-of-two steps
-                              // of the node's byte grid, the primitive boxes of up to four children as bytes on it, plane by plane (lo.x of
-                              // the four, hi.x, lo.y, hi.y, lo.z, hi.z), and their links (dwords 10..13); a link is an inner node's index,
-                              // kLinkLeaf | (pairs - 1) << 28 | first pair, or kLinkNone
-    const float4* pairs;      // kPairQuads x float4 per two consecutive primitives of a leaf (see triangle_pair_eval)
-    const float4* slots;      // 3 x float4 per rrt_slot
-    const float4* plain;      // scenes whose textures are all Constant, without bump maps and media: 2 x float4 per slot holding all
-                              // that shading a hit on it needs - (unit normal | -, kind / material type / sphere index), (the
-                              // material's colour, its roughness or refractive index) - one fetch instead of slot -> material -> texture
-    const float4* tri_shade;  // 4 x float4 per rrt_tri_shade
-    const rrt_sphere* spheres;
-    const rrt_medium* media;
-    const float4* btris;
-    const float4* btri_shade;
-    const rrt_material* materials;
-    const rrt_texture* textures;
-    const uint8_t* texels;
-    const rrt_light* lights;
-    const float4* guards;     // shallow trees: the grazing guard's table - a header of two float4, then one scaled plane normal per
-                              // distinct triangle plane of the scene that is not perpendicular to an axis (see grazes_a_plane)
-    uint32_t n_nodes, n_slots, n_lights, is_list;
-    uint32_t root_link;  // clean trees: where the walk starts (see walk_step)
-    rrt_camera cam;
-
+// The scene's arrays (SceneData, rrt_layout.hpp) as the kernels address them.
+struct DScene : SceneData {
     RRT_DEV cv4p c_nodes() const { return (cv4p)(const void*)nodes; }
     RRT_DEV cv4p c_pairs() const { return (cv4p)(const void*)pairs; }
     RRT_DEV cv4p c_slots() const { return (cv4p)(const void*)slots; }

@@ -210,11 +210,6 @@ RRT_DEV f3 sample_scatter_direction(const DScene& sc, f3 n, f3 from, Rng& g, con
     return d;
 }
 
-// DScene::plain, word 3 of a slot's first quad: bits 0..2 material type, 3..4 primitive kind, 5.. sphere index
-#define RRT_PLAIN_TYPE(bits) ((bits) & 7u)
-#define RRT_PLAIN_KIND(bits) (((bits) >> 3) & 3u)
-#define RRT_PLAIN_AUX(bits) ((bits) >> 5)
-#define RRT_PLAIN_BITS(type, kind, aux) ((type) | ((kind) << 3) | ((aux) << 5))
 
 // ---- materials (material.rs:15-54) -----------------------------------------------------------------------------------------
 RRT_DEV f3 reflect_ref(f3 v, f3 n) { return v - 2.0f * dot3(v, n) * n; }

@@ -279,8 +279,16 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect_stream(DScene sc, con
 
 namespace rrt {
 
-hipError_t launch_trace_stream(int mode, uint32_t features, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const TraceArgs& ta, float* slab,
+static DScene view_of(const SceneData& d) {
+    DScene v;
+    static_cast<SceneData&>(v) = d;
+    return v;
+}
+
+hipError_t launch_trace_stream(int mode, uint32_t features, dim3 grid, hipStream_t st, const SceneData& scene, const TraceArgs& ta, float* slab,
                                unsigned long long* counters, uint32_t* item_counter) {
+    const DScene sc = view_of(scene);
+    const size_t lds = (size_t)kTraceBlock * ta.stack_depth * sizeof(uint32_t) + kCoopBytesPerWave;
     constexpr uint32_t kPlain = F_SPHERE;
 #define RRT_GO(MODE)                                                                                                                       \
     do {                                                                                                                                   \
@@ -295,8 +303,10 @@ hipError_t launch_trace_stream(int mode, uint32_t features, dim3 grid, size_t ld
     return hipGetLastError();
 }
 
-hipError_t launch_intersect_stream(int mode, dim3 grid, size_t lds, hipStream_t st, const DScene& sc, const float* o, const float* d, size_t n, float t_min,
+hipError_t launch_intersect_stream(int mode, dim3 grid, hipStream_t st, const SceneData& scene, const float* o, const float* d, size_t n, float t_min,
                                    float t_max, uint32_t seed, uint32_t lds_entries, uint32_t run, uint32_t coop_lanes, int* prim, float* t_hit) {
+    const DScene sc = view_of(scene);
+    const size_t lds = (size_t)kTraceBlock * lds_entries * sizeof(uint32_t) + kCoopBytesPerWave;
 #define RRT_GO(MODE) hipLaunchKernelGGL((k_intersect_stream<MODE>), grid, dim3(kTraceBlock), lds, st, sc, o, d, n, t_min, t_max, seed, lds_entries, run, coop_lanes, prim, t_hit)
     if (mode == kAabbClean) RRT_GO(kAabbClean);
     else if (mode == RRT_AABB_REFERENCE) RRT_GO(RRT_AABB_REFERENCE);

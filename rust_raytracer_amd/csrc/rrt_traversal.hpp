@@ -7,18 +7,6 @@
 
 namespace rrt {
 
-// ---- scene features a kernel variant is compiled for ------------------------------------------------------------------
-// The host picks the smallest variant that covers the scene, so scenes without media / image textures / bump maps do not
-// carry that code (registers, instruction cache) through the inner loop.
-enum : uint32_t {
-    F_SPHERE = 1u,  // sphere primitives (or sphere lights)
-    F_MEDIUM = 2u,  // ConstantMedium primitives and the Isotropic phase function
-    F_TEX = 4u,     // textures other than Constant (needs uv / world point in texture lookups)
-    F_BUMP = 8u,    // bump maps (needs pu, pv)
-    F_ALL = 15u,    // all of the above
-    F_NESTED = 16u, // media whose boundary is a medium
-    F_EVERY = 31u
-};
 
 
 
@@ -70,7 +58,6 @@ RRT_DEV void test_slot(const DScene& sc, uint32_t s, const Ray& r, float t_min, 
 // accepted in leaf order (A, then B against the distance A may have shortened), so the outcome equals two single tests.
 typedef float v2f __attribute__((ext_vector_type(2)));
 RRT_DEV v2f splat2(float x) { return v2f{x, x}; }
-constexpr uint32_t kPairQuads = 8;  // float4 per pair record: six of primitive data, then the padded box of the two primitives (lo, hi)
 struct PairEval {
     v2f t, u, v, det;
     bool ok_a, ok_b;  // every acceptance test of Triangle::hit except `t < t_max`
@@ -144,7 +131,6 @@ RRT_DEV void triangle_pair_hit(v4f q0, v4f q1, v4f q2, v4f q3, v4f q4, v4f q5, c
     }
 }
 
-#define RRT_KIND_NONE 3u  // second half of an odd leaf's last pair
 
 template <uint32_t FEAT>
 RRT_DEV void test_pair(const DScene& sc, cv4p rec, const Ray& r, float t_min, const Rng& key, uint32_t depth, Hit& h) {
@@ -182,7 +168,6 @@ RRT_DEV float ord_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ?
 // lane is untouched, so results are those of closest_hit.
 //
 // `coop` is this wave's LDS area: 64 x u64 keys followed by 64 x (slot, det, u, v).
-constexpr uint32_t kCoopBytesPerWave = 64 * 8 + 64 * 16 + 128 * 4;  // closest keys, hit payloads, item list
 
 // Tests up to 64 listed (owner lane, pair position) items, one per lane, for coop_leaves().
 template <uint32_t FEAT, bool CLEAN>
@@ -488,20 +473,6 @@ RRT_DEV void triangle_uvdet(f3 v0, f3 e1, f3 e2, const Ray& r, float* u, float* 
 // reports, per light, the distance at which the ray meets the light's own primitive (any distance in (t_min, t_max), whether
 // or not something nearer hides it, and whether or not the leaf's box test let the ray in: Shape::pdf asks the shape, not
 // the tree), and the caller finishes the previous bounce's throughput from that.  Same tests, same numbers, run once.
-constexpr uint32_t kLeafDirect = 0x40000000u;  // in a shallow tree's leaf node, beside the pair count: the leaf's FIRST record is tested directly
-// A pair record's last two words are a lane mask for the harvesting query: all ones when the pair holds a light's primitive (lanes that
-// only collect light distances stay), zero when it does not (they are struck) - two words, so that the scalar unit takes them as one
-// 64-bit operand.
-constexpr uint32_t kPairLitMask = 0xffffffffu;
-// The half-width of a padding record's box (the host evens out a shallow leaf's number of sifted records with one): negative, so the
-// near distance lies beyond the far one on every axis the ray moves along, and no ray meets it.
-constexpr uint32_t kPadBoxBits = 0xbf800000u;  // -1.0f
-constexpr uint32_t kSiftCap = 512;  // items the candidate list holds (the CAP template argument below; a caller short of LDS passes less)
-constexpr uint32_t kHarvestLights = 3;
-constexpr uint32_t sift_bytes(uint32_t cap) { return 64 * 8 + cap * 4; }
-constexpr uint32_t kSiftBytesPerWave = sift_bytes(kSiftCap);
-constexpr uint32_t kHarvestBytesPerWave = 64 * kHarvestLights * 4;
-#define RRT_PAIR_LIGHT(info) (((info) >> 24) & 15u)  // device-only bits of a pair record's info words: light number + 1
 
 template <uint32_t FEAT, bool HARVEST, uint32_t CAP = kSiftCap>
 RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max, const Rng& key, uint32_t depth, const uint32_t* items, uint32_t n_items,

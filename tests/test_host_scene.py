@@ -564,6 +564,36 @@ def test_scene_description_whose_links_are_no_tree_is_refused():
     assert rc == 1 and "slot range" in msg
 
 
+def test_what_a_scene_would_upload_is_worked_out_without_a_device():
+    """rrt_scene_check runs the CPU half of rrt_scene_create alone: the records, the kernel variant and the traversal choices of the
+    shipped scenes and of synthetic ones, with no GPU in the box."""
+    import orc
+    import synth
+
+    F_SPHERE, F_MEDIUM, F_TEX, F_BUMP = 1, 2, 4, 8
+    c = rrt.HostScene.load(orc.asset("Cornell_Box_With_Sphere.json")).check()
+    # one leaf (the reference's sweep does not split it), its lights among its primitives: the harvesting query, one stack entry
+    assert c["node_records"] == 1 and c["harvest"] and not c["deep"] and not c["clean"] and c["stack_depth"] == 1
+    assert c["features"] == F_SPHERE and c["plain_records"] > 0 and c["guard_entries"] >= 5
+    # the sphere gets a record of its own and is tested directly; the triangles share records two by two, and the sifted records are even
+    hs = rrt.HostScene.load(orc.asset("Cornell_Box_With_Sphere.json"))
+    n_tri = int((hs.slots()["info"] >> 30 == 0).sum())
+    assert (n_tri + 1) // 2 + 1 <= c["pair_records"] <= n_tri + 2 and (c["pair_records"] - 1) % 2 == 0
+    g = rrt.HostScene.load(orc.asset("Globe.json")).check()
+    assert g["features"] & F_TEX and g["features"] & F_BUMP and g["plain_records"] == 0
+    e = rrt.HostScene.load(orc.asset("Example_Spec.json")).check()
+    assert e["features"] & F_MEDIUM and not e["harvest"] and not e["deep"]
+    assert len({c["desc_hash"], g["desc_hash"], e["desc_hash"]}) == 3
+    # a mesh: the reference's tree is deep (the streaming kernels, no guard table); as a List it is one leaf of many pair records
+    t = synth.host_scene(synth.terrain_desc(24, seed=2))
+    d = t.check()
+    assert d["deep"] and d["guard_entries"] == 0 and d["node_records"] == t.desc.n_nodes and d["stack_depth"] <= t.desc.bvh_depth
+    assert d["pair_records"] >= (t.desc.n_slots + 1) // 2
+    # the same description twice: the same hash; a NULL layout only checks
+    assert synth.host_scene(synth.terrain_desc(24, seed=2)).check()["desc_hash"] == d["desc_hash"]
+    assert rrt.lib().rrt_scene_check(C.byref(t.desc), None) == 0
+
+
 def test_rust_bindings_agree_with_the_header_and_the_python_bindings():
     """rrt-sys/src/lib.rs cannot be compiled here (no Rust toolchain), so it is read as text: every function the header declares
     must be declared there with the same number of parameters, and every struct's size and field offsets written there must be the
