@@ -149,10 +149,11 @@ int rrt::render_passes(rrt_scene* s, const rrt_render_params* p, float* d_rgb_su
     ta.stack_depth = s->deep && s->stack_depth > s->lds_stack ? s->lds_stack : s->stack_depth;
     // Lanes at a leaf / finished lanes that trigger a leaf / shading phase.  Reference trees (a lane waits at its leaf), measured on a
     // 500 000-triangle mesh, 1024x1024 @ 64 spp: 8/16 -> 172 ms, 16/16 -> 147 ms, 24/16 -> 140 ms, 32/16 -> 143 ms, 16/8 -> 154 ms,
-    // 16/32 -> 152 ms.  Clean trees (a lane keeps its leaf and walks on, see walk_step): the sooner a held leaf is tested the fewer
-    // nodes are visited with a stale closest distance; 500 000 triangles 1024x1024 @ 16 / 10 M triangles 3840x2160 @ 8:
-    // 2 -> 37.2 / 267.6 ms, 8 -> 38.0 / 274.9, 24 -> 39.6 / 280.4, 40 -> 42.9 / 301.7 (without holding: 40.0 / 286.1).
-    ta.coop_lanes = s->clean ? 2 : 24;
+    // 16/32 -> 152 ms.  Clean trees (a lane keeps up to two leaves and walks on, see walk_step): the number counts the lanes that cannot
+    // take another leaf (two held, or at the end of their walk with one).  About four walks end per turn of the wave's loop, so nearly
+    // every turn has a phase whatever the number is, and making those lanes wait costs more than fuller phases save: 10 M triangles
+    // at 3840x2160 @ 16: 1 -> 319.0 ms, 2 -> 321.1, 4 -> 320.2, 8 -> 321.6, 16 -> 335.5 (one held leaf, phases at two holders: 341).
+    ta.coop_lanes = s->clean ? 1 : 24;
     ta.shade_lanes = 16;
     // Node steps per turn of k_trace_stream's loop (the bookkeeping of a turn - the ballots, the phase decisions - costs a quarter of a
     // node step).  10 M triangles at 3840x2160@8 / 500 000 triangles at 1024x1024@32, persistent grid: 2 -> 275.9 / 57.4 ms, 3 -> 246.8 /

@@ -169,15 +169,19 @@ __global__ __launch_bounds__(kTraceBlock, RRT_TRACE_MIN_WAVES) void k_trace_stre
         }
         probe.walked(lane);
         // (clean trees: lanes that hold a leaf count, whether they still walk or not)
+        // (clean trees: a phase tests every held leaf; what calls for one are the lanes that cannot take another leaf - two held, or
+        // standing at a third, or at the end of their walk)
         const unsigned long long at_leaf = RRT_BALLOT(AABB_MODE == kAabbClean ? w.held != 0u : st == LEAF);
-        if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= ta.coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
+        const unsigned long long pressing = AABB_MODE == kAabbClean ? RRT_BALLOT(w.held2 != 0u || st == LEAF) : at_leaf;
+        if (at_leaf != 0ull && ((uint32_t)__popcll(pressing) >= ta.coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
             probe.leaf_phase_begins(lane);
             if (AABB_MODE == kAabbClean) {  // every lane's held leaf, see walk_step
                 const bool has = w.held != 0u;
-                coop_leaves<FEAT, true>(sc, r, RRT_T_MIN, g, depth, has, link_first_pair(w.held), link_pairs(w.held), w.h, coop);
+                coop_leaves<FEAT, true>(sc, r, RRT_T_MIN, g, depth, has, link_first_pair(w.held), link_pairs(w.held), link_first_pair(w.held2),
+                                        w.held2 != 0u ? link_pairs(w.held2) : 0u, w.h, w.hprim, coop);
                 if (has) st = walk_after_held(w, stack) ? (w.running ? WALK : LEAF) : READY;
             } else {
-                coop_leaves<FEAT, false>(sc, r, RRT_T_MIN, g, depth, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
+                coop_leaves<FEAT, false>(sc, r, RRT_T_MIN, g, depth, st == LEAF, w.first_pair, w.n_pairs, 0u, 0u, w.h, w.hprim, coop);
                 if (st == LEAF) {
                     walk_resume(w, stack);
                     st = w.running ? WALK : READY;
@@ -262,10 +266,11 @@ __global__ __launch_bounds__(kTraceBlock) void k_intersect_stream(DScene sc, con
         if (at_leaf != 0ull && ((uint32_t)__popcll(at_leaf) >= coop_lanes || RRT_BALLOT(st == WALK) == 0ull)) {
             if (AABB_MODE == kAabbClean) {
                 const bool has = w.held != 0u;
-                coop_leaves<F_EVERY, true>(sc, r, t_min, g, 0, has, link_first_pair(w.held), link_pairs(w.held), w.h, coop);
+                coop_leaves<F_EVERY, true>(sc, r, t_min, g, 0, has, link_first_pair(w.held), link_pairs(w.held), link_first_pair(w.held2),
+                                           w.held2 != 0u ? link_pairs(w.held2) : 0u, w.h, w.hprim, coop);
                 if (has) st = walk_after_held(w, stack) ? (w.running ? WALK : LEAF) : READY;
             } else {
-                coop_leaves<F_EVERY, false>(sc, r, t_min, g, 0, st == LEAF, w.first_pair, w.n_pairs, w.h, coop);
+                coop_leaves<F_EVERY, false>(sc, r, t_min, g, 0, st == LEAF, w.first_pair, w.n_pairs, 0u, 0u, w.h, w.hprim, coop);
                 if (st == LEAF) {
                     walk_resume(w, stack);
                     st = w.running ? WALK : READY;

@@ -171,14 +171,18 @@ RRT_DEV float ord_float(uint32_t k) { return __uint_as_float((k & 0x80000000u) ?
 
 // Tests up to 64 listed (owner lane, pair position) items, one per lane, for coop_leaves().
 template <uint32_t FEAT, bool CLEAN>
-RRT_DEV void coop_group(const DScene& sc, const Ray& r, float t_min, const Rng& key, uint32_t depth, uint32_t first_pair, const Hit& h,
-                        const uint32_t* items, uint32_t n_items, unsigned long long* best, v4f* payload) {
+RRT_DEV void coop_group(const DScene& sc, const Ray& r, float t_min, const Rng& key, uint32_t depth, uint32_t first_pair, uint32_t n_pairs,
+                        uint32_t first_pair2, const Hit& h, const uint32_t* items, uint32_t n_items, unsigned long long* best, v4f* payload) {
     const uint32_t lane = threadIdx.x & 63u;
     const bool have = lane < n_items;
     const uint32_t item = have ? items[lane] : lane;
     const int owner = (int)(item & 63u);
-    const uint32_t k = item >> 6;  // position of the pair in its leaf
-    const uint32_t o_first = (uint32_t)__shfl((int)first_pair, owner);
+    const uint32_t k = item >> 6;  // position of the pair in its leaf (clean trees: in the owner's two held leaves, one after the other)
+    uint32_t o_pair = (uint32_t)__shfl((int)first_pair, owner) + k;
+    if (CLEAN) {
+        const uint32_t o_n = (uint32_t)__shfl((int)n_pairs, owner), o_first2 = (uint32_t)__shfl((int)first_pair2, owner);
+        if (k >= o_n) o_pair = o_first2 + (k - o_n);
+    }
     Ray ro;
     ro.o = mk3(__shfl(r.o.x, owner), __shfl(r.o.y, owner), __shfl(r.o.z, owner));
     ro.d = mk3(__shfl(r.d.x, owner), __shfl(r.d.y, owner), __shfl(r.d.z, owner));
@@ -197,7 +201,7 @@ RRT_DEV void coop_group(const DScene& sc, const Ray& r, float t_min, const Rng& 
     hh.u = hh.v = hh.det = 0.0f;
     unsigned long long mykey = ~0ull;
     if (have) {
-        const cv4p rec = sc.c_pairs() + kPairQuads * (o_first + k);
+        const cv4p rec = sc.c_pairs() + kPairQuads * o_pair;
         test_pair<FEAT>(sc, rec, ro, t_min, okey, odepth, hh);
         if (hh.slot >= 0) {
             uint32_t pos = (uint32_t)hh.slot;
@@ -216,24 +220,25 @@ RRT_DEV void coop_group(const DScene& sc, const Ray& r, float t_min, const Rng& 
 
 // The cooperative leaf phase: every pending lane stands at a leaf (first_pair, n_pairs); the wave lists all (lane, pair) items
 // - position by position, compacted with a ballot and a prefix count, no cross-lane shuffles - and tests them 64 at a time, any
-// lane testing any owner's pair.  Must be called by all 64 lanes.
+// lane testing any owner's pair.  Must be called by all 64 lanes.  Clean trees: a lane may bring a second leaf (first_pair2, n_pairs2;
+// n_pairs2 = 0 without one), and `hprim` is the scene position + 1 of the shape its hit so far is on (0 without a hit): kept by the
+// caller from phase to phase.
 template <uint32_t FEAT, bool CLEAN>
 RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng& key, uint32_t depth, bool pending, uint32_t first_pair, uint32_t n_pairs,
-                         Hit& h, unsigned char* coop) {
+                         uint32_t first_pair2, uint32_t n_pairs2, Hit& h, uint32_t& hprim, unsigned char* coop) {
     const uint32_t lane = threadIdx.x & 63u;
     unsigned long long* best = (unsigned long long*)coop;
     v4f* payload = (v4f*)(coop + 64 * 8);
     uint32_t* items = (uint32_t*)(coop + 64 * 8 + 64 * 16);  // 128 places: a group being filled plus one position's worth of items
     // Ties: in the reference's tree the leaf visited first wins, so what the owner already holds gets position 0; in a clean
     // tree the shape that is first in scene order wins wherever it sits, so positions are shape numbers throughout.
-    uint32_t held = 0u;
-    if (CLEAN && h.slot >= 0) held = __float_as_uint(sc.c_slots()[3 * h.slot].w) + 1u;
-    const unsigned long long init = ((unsigned long long)ord_bits(h.t) << 32) | held;
+    const unsigned long long init = ((unsigned long long)ord_bits(h.t) << 32) | (CLEAN ? hprim : 0u);
+    const uint32_t n_all = n_pairs + (CLEAN ? n_pairs2 : 0u);
     best[lane] = init;
     __threadfence_block();
     uint32_t count = 0;
     for (uint32_t k = 0;; ++k) {
-        const bool has = pending && k < n_pairs;
+        const bool has = pending && k < n_all;
         const unsigned long long bal = RRT_BALLOT(has);
         if (bal == 0ull) break;
         if (has) {
@@ -243,7 +248,7 @@ RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng&
         count += (uint32_t)__popcll(bal);
         __threadfence_block();
         if (count >= 64u) {
-            coop_group<FEAT, CLEAN>(sc, r, t_min, key, depth, first_pair, h, items, 64u, best, payload);
+            coop_group<FEAT, CLEAN>(sc, r, t_min, key, depth, first_pair, n_pairs, first_pair2, h, items, 64u, best, payload);
             count -= 64u;
             const uint32_t moved = lane < count ? items[64u + lane] : 0u;
             __threadfence_block();
@@ -251,7 +256,7 @@ RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng&
             __threadfence_block();
         }
     }
-    if (count != 0u) coop_group<FEAT, CLEAN>(sc, r, t_min, key, depth, first_pair, h, items, count, best, payload);
+    if (count != 0u) coop_group<FEAT, CLEAN>(sc, r, t_min, key, depth, first_pair, n_pairs, first_pair2, h, items, count, best, payload);
     if (pending && best[lane] != init) {
         const v4f w = payload[lane];
         h.t = ord_float((uint32_t)(best[lane] >> 32));
@@ -259,6 +264,7 @@ RRT_DEV void coop_leaves(const DScene& sc, const Ray& r, float t_min, const Rng&
         h.det = w.y;
         h.u = w.z;
         h.v = w.w;
+        if (CLEAN) hprim = (uint32_t)best[lane];
     }
 }
 
@@ -268,7 +274,8 @@ struct Walk {
     bool running;  // has a node to visit
     bool pending;  // stands at a leaf (first_pair, n_pairs) that the next cooperative phase tests
     uint32_t first_pair, n_pairs;
-    uint32_t held;  // clean trees: the link of a leaf reached but not yet tested (0: none), see walk_step
+    uint32_t held, held2;  // clean trees: the links of up to two leaves reached but not yet tested (0: none), see walk_step
+    uint32_t hprim;        // clean trees: scene position + 1 of the shape the hit so far is on (ties go by scene order, see coop_leaves)
     f3 inv;
     uint32_t down;  // bit c: the ray runs towards smaller coordinates on axis c
     Hit h;
@@ -299,7 +306,7 @@ RRT_DEV void walk_begin(const DScene& sc, Walk& w, bool active, const Ray& r, fl
     w.cur = sc.root_link;  // 0 for the reference's trees
     w.pending = false;
     w.first_pair = w.n_pairs = 0;
-    w.held = 0u;
+    w.held = w.held2 = w.hprim = 0u;
     w.running = active && sc.n_nodes != 0 && w.cur != kLinkNone;  // kLinkNone: a clean tree whose only leaf is empty
     w.inv = mk3(1.0f / r.d.x, 1.0f / r.d.y, 1.0f / r.d.z);
     if (AABB_MODE == kAabbClean) {
@@ -323,19 +330,20 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, con
         // One 64-byte fetch brings the boxes of up to four children: only children the ray meets are ever fetched themselves,
         // and leaves are not fetched at all (their pair range sits in the link).  Children are visited nearest entry first;
         // the result does not depend on the order (ties go by scene order, see coop_leaves).
-        // A lane that reaches a leaf does not stop for it: it keeps the leaf's link ("held") and walks on, and stops only at the
-        // NEXT leaf (or when its walk is over).  The wave's cooperative phases test the held leaves of ALL lanes, walking or not,
+        // A lane that reaches a leaf does not stop for it: it keeps the leaf's link ("held"), and a second leaf's too, and walks on,
+        // and stops only at the THIRD leaf (or when its walk is over).  The wave's cooperative phases test the held leaves of ALL lanes, walking or not,
         // so a phase serves more lanes and fewer lanes stand idle waiting for one.  The nodes visited meanwhile are culled with
         // the closest distance known before the held leaf's test - a few more visits, the same result: in a clean tree the
         // answer does not depend on the order of the tests (nearest hit, ties by scene order).
         if (w.cur & kLinkLeaf) {
-            if (w.held == 0u) {
-                w.held = w.cur;
+            if (w.held2 == 0u) {
+                if (w.held == 0u) w.held = w.cur;
+                else w.held2 = w.cur;
                 if (w.sp == 0) w.running = false;
                 else w.cur = stack_pop(stack, w.sp);
                 return;
             }
-            w.pending = true;  // (w.cur keeps the second leaf's link)
+            w.pending = true;  // (w.cur keeps the third leaf's link)
             w.running = false;
             return;
         }
@@ -420,10 +428,10 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, con
 // Clean trees: the pair range of a leaf link.
 RRT_DEV uint32_t link_first_pair(uint32_t link) { return link & 0x0fffffffu; }
 RRT_DEV uint32_t link_pairs(uint32_t link) { return ((link >> 28) & 7u) + 1u; }
-// Clean trees, after a cooperative phase that tested this lane's held leaf: a lane that stood at a second leaf now holds
+// Clean trees, after a cooperative phase that tested this lane's held leaves: a lane that stood at a third leaf now holds
 // that one and walks on.  Returns false when nothing is left to do for the query (no node to visit, no leaf held).
 RRT_DEV bool walk_after_held(Walk& w, const WalkStack& stack) {
-    w.held = 0u;
+    w.held = w.held2 = 0u;
     if (w.pending) {
         w.held = w.cur;
         w.pending = false;
