@@ -16,6 +16,63 @@ sys.path.insert(0, ROOT)
 import bench  # noqa: E402  (kernel_source_hash, the peak figures)
 
 src, name, prefix = sys.argv[1], sys.argv[2], sys.argv[3]
+
+
+def mesh_record():
+    """The c5 record, from tools/profile_mesh.sh (+ profile_mesh_mem.sh into the same directory): one launch of k_trace_stream."""
+    c = {}
+    for line in open(os.path.join(src, "pmc_summary.txt")):
+        parts = line.split()
+        if len(parts) == 2 and not line.startswith("=="):
+            try:
+                c[parts[0]] = float(parts[1])
+            except ValueError:
+                pass
+    run = open(os.path.join(src, "run_trace.txt")).read()
+    m = re.search(r"(\d+)x(\d+)@(\d+): ([0-9.]+) ms\s+rays=(\d+)", run)
+    W, spp, rays = int(m.group(1)), int(m.group(3)), int(m.group(5))
+    kernel = None
+    for row in csv.DictReader(open(os.path.join(src, "kernel_stats.csv"))):
+        if "k_trace_stream" in row["Name"]:
+            kernel = row
+            break
+    calls, total_s = int(kernel["Calls"]), float(kernel["TotalDurationNs"]) * 1e-9
+    hbm = (2.0 * c.get("FETCH_SIZE", 0.0) + c.get("WRITE_SIZE", 0.0)) * 1024.0
+    rec = {
+        "spp": spp, "width": W,
+        "kernel": re.sub(r"\(rrt::DScene.*", "", kernel["Name"]).replace("void (anonymous namespace)::", ""),
+        "kernel_source_hash": bench.kernel_source_hash(),
+        "launches_profiled": calls,
+        "kernel_ms_in_the_trace_run": float(kernel["AverageNs"]) * 1e-6,
+        "rays_profiled": rays * calls,
+        "SQ_INSTS_VALU": c["SQ_INSTS_VALU"], "SQ_INSTS_SALU": c.get("SQ_INSTS_SALU"), "SQ_INSTS_LDS": c.get("SQ_INSTS_LDS"),
+        "SQ_ACTIVE_INST_VALU": c["SQ_ACTIVE_INST_VALU"], "SQ_THREAD_CYCLES_VALU": c["SQ_THREAD_CYCLES_VALU"],
+        "valu_wave_instr_per_ray": c["SQ_INSTS_VALU"] / (rays * calls),
+        "lane_utilisation": c["SQ_THREAD_CYCLES_VALU"] / (64.0 * c["SQ_ACTIVE_INST_VALU"]),
+        "valu_busy_frac": c["SQ_ACTIVE_INST_VALU"] * 4.0 / (bench.SIMDS * total_s * bench.PEAK_CLOCK_GHZ * 1e9),
+        "fetch_size_kb_total": c.get("FETCH_SIZE"), "write_size_kb_total": c.get("WRITE_SIZE"),
+        "TCC_HIT_sum": c.get("TCC_HIT_sum"), "TCC_MISS_sum": c.get("TCC_MISS_sum"),
+        "TCP_TOTAL_CACHE_ACCESSES_sum": c.get("TCP_TOTAL_CACHE_ACCESSES_sum"),
+        # (TA_BUSY_avr is a mean over the address units; GRBM_GUI_ACTIVE comes summed over the eight XCDs)
+        "TA_BUSY_avr_frac": (8.0 * c["TA_BUSY_avr"] / c["GRBM_GUI_ACTIVE"]) if c.get("TA_BUSY_avr") and c.get("GRBM_GUI_ACTIVE") else None,
+        "hbm_bytes_per_launch": hbm / calls,
+        "hbm_bytes_per_ray": hbm / (rays * calls),
+        "correction": "FETCH_SIZE x2 (gfx950 counts 128-B read requests as 64 B); WRITE_SIZE taken as reported",
+        "source": "%s_pmc_summary.txt (rocprofv3 --pmc, separate passes of `python3 tools/perf_mesh.py 2236 3840 2160 16 tight clean`)" % prefix,
+    }
+    return rec
+
+
+if name == "c5":
+    rec = mesh_record()
+    path = os.path.join(ROOT, "profiles", "pmc_counters.json")
+    allrec = json.load(open(path)) if os.path.exists(path) else {}
+    allrec[name] = rec
+    with open(path, "w") as f:
+        json.dump(allrec, f, indent=1)
+        f.write("\n")
+    print(json.dumps(rec, indent=1))
+    sys.exit(0)
 counters = {}
 section = None
 for line in open(os.path.join(src, "pmc_summary.txt")):
