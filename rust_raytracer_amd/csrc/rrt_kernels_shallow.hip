@@ -311,11 +311,7 @@ __global__ __launch_bounds__(kTraceBlock, kPoolWaves) void k_trace_pool(DScene s
                 ++rays;
                 f3 thr = mk3(__uint_as_float(POOL(P_TX, slot)), __uint_as_float(POOL(P_TY, slot)), __uint_as_float(POOL(P_TZ, slot)));
                 const bool pending = HARVEST && (meta & 8u) != 0u;
-#ifdef RRT_EXP_NO_PENDING
-                if (false) {
-#else
                 if (pending) {  // aggregate.rs:79-89 for the previous bounce, now that this ray's light distances are known (thr held the numerator)
-#endif
                     const float scatter_pdf = __uint_as_float(POOL(P_PDF_T, slot));
                     const float pdf_val = mixture_value_harvested(sc, r, harvest) * 0.5f + scatter_pdf * 0.5f;  // pair_value, pdf.rs:117-119
                     thr = thr / pdf_val;

@@ -596,9 +596,6 @@ RRT_DEV v2f dot_two(f3 d, v4f xy, v4f z) {
 template <int AABB_MODE, bool ANY_ORIGIN>
 RRT_DEV bool grazes_a_plane(const DScene& sc, const Ray& r) {
     if (AABB_MODE == kAabbExhaustive) return false;  // (that mode has no shortcut to guard)
-#ifdef RRT_NO_GUARD
-    return false;
-#endif
     // (the header and the first two general entries - there are always two, inert ones if need be - are fetched together)
     const cv4p g = sc.c_guards();
     const v4f h0 = g[0], h1 = g[1], h2 = g[2], Gxy = g[3], Gz = g[4];
@@ -634,16 +631,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
     uint32_t* items = (uint32_t*)(area + 64 * 8);
     // a ray that runs too close to a triangle's plane for the padded boxes to be trusted (see grazes_a_plane) gets NaN on all
     // three axes below: every pair box is then met, and so is every node's primitive box
-#ifdef RRT_EXP_GUARD_IGNORED
-    bool graze = grazes_a_plane<AABB_MODE, ANY_ORIGIN>(sc, r);
-    {
-        unsigned long long gm = RRT_BALLOT(graze);
-        asm volatile("" : "+s"(gm));  // computed, kept alive, not used
-        graze = false;
-    }
-#else
     const bool graze = grazes_a_plane<AABB_MODE, ANY_ORIGIN>(sc, r);
-#endif
     const f3 inv = exact_rcp3(r.d);  // = 1.0f / r.d, bit for bit (see exact_rcp)
     // for the pair boxes: centre * finv + noi (see pair_box_overlap_ch); an axis whose product origin * inv is not finite (zero or
     // denormal direction component) gets NaN, which the interval test ignores: that axis then constrains nothing
