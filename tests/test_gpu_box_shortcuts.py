@@ -139,3 +139,64 @@ def test_exhaustive_mode_renders_the_oracle_frame(gpu, case):
         same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
         assert same.all(), "%d of %d values differ (mode %d)" % ((~same).sum(), same.size, mode)
         assert st["rays"] == int(st_ref[0])
+
+
+def _awkward_desc(flat):
+    """slats as a List, plus the triangles the guard's bound is weakest for: a sliver (its two edges at v0 almost parallel), a
+    triangle a thousand times the size of the rest, a tiny one and - flat = True - a triangle without area (which makes the
+    library give up every shortcut: no ray can be trusted to stay clear of a plane that has no direction)."""
+    d = synth.slats_desc(n=12, aggregate=0, spheres=2)
+    ident_r, ident_s = [0.0, 0.0, 0.0], [1.0, 1.0, 1.0]
+    one = np.array([[0, 1, 2]], dtype=np.int32)
+
+    def tri(v, material=0):
+        v = np.asarray(v, dtype=np.float64)
+        return {"type": "mesh", "object": {"vertices": v, "tex": np.zeros((0, 2)), "vidx": one, "tidx": np.full_like(one, -1)},
+                "cull": False, "material": material, "transform": ([0.0, 0.0, 0.0], ident_r, ident_s)}
+
+    d["shapes"].insert(3, tri([[-1.0, 0.3, 0.4], [1.0, 0.3, 0.4], [0.9, 0.3001, 0.45]]))          # sliver
+    if flat:
+        d["shapes"].insert(5, tri([[0.2, 0.2, 0.1], [0.4, 0.4, 0.3], [0.6, 0.6, 0.5]], material=1))  # three points on a line
+    d["shapes"].insert(7, tri([[-900.0, -3.0, -700.0], [800.0, -3.0, -900.0], [100.0, -3.5, 950.0]]))  # far larger than the rest
+    d["shapes"].insert(9, tri([[0.1, -0.2, 1.0], [0.1003, -0.2, 1.0], [0.1, -0.1996, 1.0002]], material=1))  # tiny
+    return d
+
+
+@pytest.mark.parametrize("flat", [False, True])
+def test_guard_with_slivers_giants_and_odd_ray_lengths(gpu, flat):
+    """The guard's bound scales with the angle between a triangle's edges, the ratio of their lengths, the triangle's size against
+    the scene's and the ray's distance from the scene; and a direction whose squared length leaves the float range must not
+    fool its arithmetic.  All three modes against the oracle on grazing rays of every length, from near and from far."""
+    d = _awkward_desc(flat)
+    o, g = orc.OracleScene(d), rrt.Scene(synth.host_scene(d))
+    assert g.host.desc.n_nodes == 1
+    slots = g.host.slots()
+    extent = 4.0  # aim at the small triangles as closely as at the giant
+    ro, rd, which, angle = raygen.triangle_outline_grazers(slots, extent, seed=11, max_triangles=64, per_edge=4)
+    rng = np.random.default_rng(3)
+    variants = [(ro, rd)]
+    for scale in (1e-18, 1e-21, 1e12, 1e18):  # squared lengths that underflow to denormals or zero, and that overflow
+        variants.append((ro, (rd.astype(np.float64) * scale).astype(np.float32)))
+    far = (ro.astype(np.float64) - rd.astype(np.float64) / np.linalg.norm(rd, axis=1, keepdims=True) * rng.choice([1e3, 1e5, 1e7], (len(ro), 1))).astype(np.float32)
+    variants.append((far, rd))
+    axis = rd.copy()
+    axis[np.arange(len(axis)), rng.integers(0, 3, len(axis))] = 0.0  # directions inside a coordinate plane
+    variants.append((ro, axis))
+    total = 0
+    for vo, vd in variants:
+        vo, vd = np.ascontiguousarray(vo), np.ascontiguousarray(vd)
+        for t_min in (0.001, 0.0):
+            p_ref, t_ref = o.intersect(vo, vd, t_min=t_min)
+            total += int((p_ref >= 0).sum())
+            for mode in MODES:
+                p, t = g.hit(vo, vd, t_min=t_min, aabb_mode=mode)
+                bad = (p != p_ref) | (bits(t) != bits(t_ref))
+                assert not bad.any(), "mode %d, t_min %g: %d of %d rays differ from the oracle (first: ray %d)" % (
+                    mode, t_min, bad.sum(), len(vo), int(np.nonzero(bad)[0][0]))
+    assert total > len(ro)
+    # and a frame through the render kernels (their rays take one precomputed reach, or work out their own)
+    ref, _ = o.render(32, 24, 6, seed=2, bg=rrt.BG_SKY)
+    for mode in MODES:
+        img, _ = g.render(width=32, height=24, samples=6, seed=2, background=rrt.BG_SKY, aabb_mode=mode)
+        same = (bits(img) == bits(ref)) | (np.isnan(img) & np.isnan(ref))
+        assert same.all(), "%d of %d values differ (mode %d)" % ((~same).sum(), same.size, mode)
