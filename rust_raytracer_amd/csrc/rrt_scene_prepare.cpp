@@ -6,6 +6,7 @@
 #include <cstring>
 #include <limits>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -415,105 +416,134 @@ int prepare_scene(const rrt_scene_desc* desc, PreparedScene* out) {
         if (!harvest) std::fill(light_of_slot.begin(), light_of_slot.end(), 0u);
         out->harvest = harvest;
         const bool clean = desc->aggregate_kind == RRT_AGGREGATE_BVH_CLEAN;
-        auto emit = [&](uint32_t ia, uint32_t ib, bool has_b) {  // ia < ib: A precedes B in leaf order
-            if (clean && has_b && desc->slots[ib].prim < desc->slots[ia].prim) std::swap(ia, ib);  // clean trees: A first in SCENE order
-            const rrt_slot& A = desc->slots[ia];
-            const rrt_slot& B = desc->slots[has_b ? ib : ia];
-            const float* av[3] = {A.v0, A.e1, A.e2};
-            const float* bv[3] = {B.v0, B.e1, B.e2};
-            for (int v = 0; v < 3; ++v)
-                for (int c = 0; c < 3; ++c) {
-                    pairs.push_back(av[v][c]);
-                    pairs.push_back(bv[v][c]);
-                }
-            pairs.push_back(put_u((A.info & ~(15u << 24)) | (light_of_slot[ia] << 24)));
-            pairs.push_back(put_u(has_b ? ((B.info & ~(15u << 24)) | (light_of_slot[ib] << 24)) : (RRT_KIND_NONE << 30)));
-            pairs.push_back(put_u(ia));
-            pairs.push_back(put_u(has_b ? ib : ia));
-            pairs.push_back(put_u(A.prim));
-            pairs.push_back(put_u(B.prim));
-            float box[8], box_b[8];
-            pair_box(desc, ia, 1, pad, box);
-            if (has_b) {
-                pair_box(desc, ib, 1, pad, box_b);
-                for (int c = 0; c < 3; ++c) {
-                    box[c] = std::fmin(box[c], box_b[c]);
-                    box[4 + c] = std::fmax(box[4 + c], box_b[4 + c]);
-                }
-            }
-            const bool lit = light_of_slot[ia] != 0u || (has_b && light_of_slot[ib] != 0u);
-            const float lit_lanes = put_u(lit ? kPairLitMask : 0u);
-            const float inter[8] = {box[0], box[4], box[1], box[5], box[2], box[6], lit_lanes, lit_lanes};  // (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, lane mask in two words)
-            pairs.insert(pairs.end(), inter, inter + 8);
-        };
         auto half_area = [](const float* b) {
             const float x = b[4] - b[0], y = b[5] - b[1], z = b[6] - b[2];
             return x * y + y * z + z * x;
         };
-        std::vector<uint32_t> tri, partner;
-        std::vector<float> boxes;
-        struct Cand { float gain; uint32_t i, j; };
-        std::vector<Cand> cands;
-        for (rrt_node& n : dn) {
-            if (!(n.b & RRT_LEAF_FLAG)) continue;
-            const uint32_t first = n.a, count = n.b & ~RRT_LEAF_FLAG;
-            const uint32_t first_pair = (uint32_t)(pairs.size() / (4 * kPairQuads));
-            tri.clear();
-            for (uint32_t k = 0; k < count; ++k)
-                if (RRT_INFO_KIND(desc->slots[first + k].info) == RRT_KIND_TRIANGLE) tri.push_back(first + k);
-            const uint32_t nt = (uint32_t)tri.size();
-            // spheres and media get records of their own, at the front of the leaf; a leaf with exactly one of them (too few to fill
-            // a dense group of the sifting query; with two, Materials.json renders 1.5 % slower) has it tested by the rays' own lanes
-            // (closest_hit_sift), and says so in its node
-            const bool shallow = is_shallow(desc);  // the sifting query's trees
-            const bool direct = shallow && count - nt == 1u;
-            for (uint32_t k = 0; k < count; ++k)
-                if (RRT_INFO_KIND(desc->slots[first + k].info) != RRT_KIND_TRIANGLE) emit(first + k, first + k, false);
-            boxes.resize((size_t)nt * 8);
-            for (uint32_t i = 0; i < nt; ++i) pair_box(desc, tri[i], 1, pad, &boxes[(size_t)i * 8]);
-            // gain of sharing a record = area of the two boxes minus the area of their union (a ray meets a box about in
-            // proportion to its area); best gains first, each triangle used once
-            cands.clear();
-            const uint32_t window = nt <= 256 ? nt : 16;  // huge leaves (a List aggregate over a mesh): nearby slots only
-            for (uint32_t i = 0; i < nt; ++i)
-                for (uint32_t j = i + 1; j < nt && j - i <= window; ++j) {
-                    float u[8];
+        // The leaves are independent of one another: large trees are matched by several threads, each over a run of consecutive
+        // nodes into a list of its own (a leaf's first pair counted within that list), and the lists are joined in node order -
+        // the same records in the same places as one thread would write.
+        auto match_leaves = [&](size_t node_lo, size_t node_hi, std::vector<float>& pairs) {
+            auto emit = [&](uint32_t ia, uint32_t ib, bool has_b) {  // ia < ib: A precedes B in leaf order
+                if (clean && has_b && desc->slots[ib].prim < desc->slots[ia].prim) std::swap(ia, ib);  // clean trees: A first in SCENE order
+                const rrt_slot& A = desc->slots[ia];
+                const rrt_slot& B = desc->slots[has_b ? ib : ia];
+                const float* av[3] = {A.v0, A.e1, A.e2};
+                const float* bv[3] = {B.v0, B.e1, B.e2};
+                for (int v = 0; v < 3; ++v)
                     for (int c = 0; c < 3; ++c) {
-                        u[c] = std::fmin(boxes[(size_t)i * 8 + c], boxes[(size_t)j * 8 + c]);
-                        u[4 + c] = std::fmax(boxes[(size_t)i * 8 + 4 + c], boxes[(size_t)j * 8 + 4 + c]);
+                        pairs.push_back(av[v][c]);
+                        pairs.push_back(bv[v][c]);
                     }
-                    const float gain = half_area(&boxes[(size_t)i * 8]) + half_area(&boxes[(size_t)j * 8]) - half_area(u);
-                    cands.push_back({gain, i, j});
+                pairs.push_back(put_u((A.info & ~(15u << 24)) | (light_of_slot[ia] << 24)));
+                pairs.push_back(put_u(has_b ? ((B.info & ~(15u << 24)) | (light_of_slot[ib] << 24)) : (RRT_KIND_NONE << 30)));
+                pairs.push_back(put_u(ia));
+                pairs.push_back(put_u(has_b ? ib : ia));
+                pairs.push_back(put_u(A.prim));
+                pairs.push_back(put_u(B.prim));
+                float box[8], box_b[8];
+                pair_box(desc, ia, 1, pad, box);
+                if (has_b) {
+                    pair_box(desc, ib, 1, pad, box_b);
+                    for (int c = 0; c < 3; ++c) {
+                        box[c] = std::fmin(box[c], box_b[c]);
+                        box[4 + c] = std::fmax(box[4 + c], box_b[4 + c]);
+                    }
                 }
-            std::stable_sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.gain > y.gain; });
-            partner.assign(nt, 0xffffffffu);
-            float leaf_box[8];
-            pair_box(desc, first, count, pad, leaf_box);
-            const float min_gain = -0.1f * half_area(leaf_box);  // a slightly larger common box still beats a second record
-            for (const Cand& c : cands) {
-                if (c.gain < min_gain) break;
-                if (partner[c.i] != 0xffffffffu || partner[c.j] != 0xffffffffu) continue;
-                partner[c.i] = c.j;
-                partner[c.j] = c.i;
+                const bool lit = light_of_slot[ia] != 0u || (has_b && light_of_slot[ib] != 0u);
+                const float lit_lanes = put_u(lit ? kPairLitMask : 0u);
+                const float inter[8] = {box[0], box[4], box[1], box[5], box[2], box[6], lit_lanes, lit_lanes};  // (lo.x, hi.x, lo.y, hi.y, lo.z, hi.z, lane mask in two words)
+                pairs.insert(pairs.end(), inter, inter + 8);
+            };
+            std::vector<uint32_t> tri, partner;
+            std::vector<float> boxes;
+            struct Cand { float gain; uint32_t i, j; };
+            std::vector<Cand> cands;
+            for (size_t node = node_lo; node < node_hi; ++node) {
+                rrt_node& n = dn[node];
+                if (!(n.b & RRT_LEAF_FLAG)) continue;
+                const uint32_t first = n.a, count = n.b & ~RRT_LEAF_FLAG;
+                const uint32_t first_pair = (uint32_t)(pairs.size() / (4 * kPairQuads));
+                tri.clear();
+                for (uint32_t k = 0; k < count; ++k)
+                    if (RRT_INFO_KIND(desc->slots[first + k].info) == RRT_KIND_TRIANGLE) tri.push_back(first + k);
+                const uint32_t nt = (uint32_t)tri.size();
+                // spheres and media get records of their own, at the front of the leaf; a leaf with exactly one of them (too few to fill
+                // a dense group of the sifting query; with two, Materials.json renders 1.5 % slower) has it tested by the rays' own lanes
+                // (closest_hit_sift), and says so in its node
+                const bool shallow = is_shallow(desc);  // the sifting query's trees
+                const bool direct = shallow && count - nt == 1u;
+                for (uint32_t k = 0; k < count; ++k)
+                    if (RRT_INFO_KIND(desc->slots[first + k].info) != RRT_KIND_TRIANGLE) emit(first + k, first + k, false);
+                boxes.resize((size_t)nt * 8);
+                for (uint32_t i = 0; i < nt; ++i) pair_box(desc, tri[i], 1, pad, &boxes[(size_t)i * 8]);
+                // gain of sharing a record = area of the two boxes minus the area of their union (a ray meets a box about in
+                // proportion to its area); best gains first, each triangle used once
+                cands.clear();
+                const uint32_t window = nt <= 256 ? nt : 16;  // huge leaves (a List aggregate over a mesh): nearby slots only
+                for (uint32_t i = 0; i < nt; ++i)
+                    for (uint32_t j = i + 1; j < nt && j - i <= window; ++j) {
+                        float u[8];
+                        for (int c = 0; c < 3; ++c) {
+                            u[c] = std::fmin(boxes[(size_t)i * 8 + c], boxes[(size_t)j * 8 + c]);
+                            u[4 + c] = std::fmax(boxes[(size_t)i * 8 + 4 + c], boxes[(size_t)j * 8 + 4 + c]);
+                        }
+                        const float gain = half_area(&boxes[(size_t)i * 8]) + half_area(&boxes[(size_t)j * 8]) - half_area(u);
+                        cands.push_back({gain, i, j});
+                    }
+                std::stable_sort(cands.begin(), cands.end(), [](const Cand& x, const Cand& y) { return x.gain > y.gain; });
+                partner.assign(nt, 0xffffffffu);
+                float leaf_box[8];
+                pair_box(desc, first, count, pad, leaf_box);
+                const float min_gain = -0.1f * half_area(leaf_box);  // a slightly larger common box still beats a second record
+                for (const Cand& c : cands) {
+                    if (c.gain < min_gain) break;
+                    if (partner[c.i] != 0xffffffffu || partner[c.j] != 0xffffffffu) continue;
+                    partner[c.i] = c.j;
+                    partner[c.j] = c.i;
+                }
+                for (uint32_t i = 0; i < nt; ++i) {
+                    if (partner[i] == 0xffffffffu) emit(tri[i], tri[i], false);
+                    else if (partner[i] > i) emit(tri[i], tri[partner[i]], true);
+                }
+                if (shallow && (((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair - (direct ? 1u : 0u)) & 1u) != 0u) {
+                    // the sifting loop takes two records per turn: an odd leaf gets a record whose box no ray meets (its half-widths are
+                    // negative).  A ray the grazing guard has taken the box tests from lists it all the same: its two primitives are
+                    // triangles without area (all zeros, slot 0), which the exact test turns down at the determinant
+                    const size_t at = pairs.size();
+                    pairs.resize(at + 4 * kPairQuads, 0.0f);
+                    for (int c = 0; c < 3; ++c) {  // written as (lo, hi) = (1, -1): becomes half-width -1, centre 0 below
+                        pairs[at + 24 + 2 * c] = 1.0f;
+                        pairs[at + 24 + 2 * c + 1] = -1.0f;
+                    }
+                }
+                n.a = first_pair;
+                n.b = RRT_LEAF_FLAG | ((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair);
+                if (direct) n.b |= kLeafDirect;  // (a shallow tree holds at most 2^25 pair records: the bit is free)
             }
-            for (uint32_t i = 0; i < nt; ++i) {
-                if (partner[i] == 0xffffffffu) emit(tri[i], tri[i], false);
-                else if (partner[i] > i) emit(tri[i], tri[partner[i]], true);
-            }
-            if (shallow && (((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair - (direct ? 1u : 0u)) & 1u) != 0u) {
-                // the sifting loop takes two records per turn: an odd leaf gets a record whose box no ray meets (its half-widths are
-                // negative).  A ray the grazing guard has taken the box tests from lists it all the same: its two primitives are
-                // triangles without area (all zeros, slot 0), which the exact test turns down at the determinant
-                const size_t at = pairs.size();
-                pairs.resize(at + 4 * kPairQuads, 0.0f);
-                for (int c = 0; c < 3; ++c) {  // written as (lo, hi) = (1, -1): becomes half-width -1, centre 0 below
-                    pairs[at + 24 + 2 * c] = 1.0f;
-                    pairs[at + 24 + 2 * c + 1] = -1.0f;
+        };
+        {
+            const size_t n_nodes = dn.size();
+            unsigned n_threads = 1;
+            if (n_nodes >= 65536) n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+            if (n_threads == 1) match_leaves(0, n_nodes, pairs);
+            else {
+                std::vector<std::vector<float>> part(n_threads);
+                std::vector<std::thread> pool;
+                auto lo_of = [&](unsigned t) { return n_nodes * t / n_threads; };
+                for (unsigned t = 0; t < n_threads; ++t) pool.emplace_back([&, t]() { match_leaves(lo_of(t), lo_of(t + 1), part[t]); });
+                for (std::thread& t : pool) t.join();
+                size_t total = 0;
+                for (const std::vector<float>& q : part) total += q.size();
+                pairs.reserve(total);
+                for (unsigned t = 0; t < n_threads; ++t) {
+                    const uint32_t base = (uint32_t)(pairs.size() / (4 * kPairQuads));
+                    for (size_t node = lo_of(t); node < lo_of(t + 1); ++node)
+                        if (dn[node].b & RRT_LEAF_FLAG) dn[node].a += base;
+                    pairs.insert(pairs.end(), part[t].begin(), part[t].end());
+                    std::vector<float>().swap(part[t]);
                 }
             }
-            n.a = first_pair;
-            n.b = RRT_LEAF_FLAG | ((uint32_t)(pairs.size() / (4 * kPairQuads)) - first_pair);
-            if (direct) n.b |= kLeafDirect;  // (a shallow tree holds at most 2^25 pair records: the bit is free)
         }
         if (is_shallow(desc)) {
             // the sifting query (shallow trees) reads a pair's box as half-widths and centres: (h.x, c.x, h.y, c.y | h.z, c.z, ...);
@@ -751,10 +781,17 @@ int prepare_scene(const rrt_scene_desc* desc, PreparedScene* out) {
         if (desc->materials[i].type == RRT_MAT_ISOTROPIC) out->features |= F_MEDIUM;
     }
     {
-        uint64_t h = 1469598103934665603ull;  // FNV-1a over everything a kernel reads
+        uint64_t h = 1469598103934665603ull;  // FNV-1a's constants over 8-byte words of everything a kernel reads (a gigabyte for 10 M triangles)
         auto mix = [&h](const void* p, size_t n) {
             const unsigned char* b = (const unsigned char*)p;
-            for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
+            size_t i = 0;
+            for (; i + 8 <= n; i += 8) {
+                uint64_t w;
+                std::memcpy(&w, b + i, 8);
+                h = (h ^ w) * 1099511628211ull;
+                h ^= h >> 29;
+            }
+            for (; i < n; ++i) h = (h ^ b[i]) * 1099511628211ull;
         };
         mix(desc->nodes, (size_t)desc->n_nodes * sizeof(rrt_node));
         mix(desc->slots, (size_t)desc->n_slots * sizeof(rrt_slot));
