@@ -381,7 +381,7 @@ std::vector<float> tight_boxes(const rrt_scene_desc* d) {
 
 }  // namespace
 
-int prepare_scene(const rrt_scene_desc* desc, PreparedScene* out) {
+int prepare_scene(const rrt_scene_desc* desc, PreparedScene* out, unsigned max_threads) {
     *out = PreparedScene();
     uint32_t tree_depth = 1;
     if (int rc = validate_desc(desc, &tree_depth)) return rc;
@@ -525,7 +525,7 @@ int prepare_scene(const rrt_scene_desc* desc, PreparedScene* out) {
         {
             const size_t n_nodes = dn.size();
             unsigned n_threads = 1;
-            if (n_nodes >= 65536) n_threads = std::min(16u, std::max(1u, std::thread::hardware_concurrency()));
+            if (n_nodes >= 65536) n_threads = std::min(max_threads ? max_threads : 16u, std::max(1u, std::thread::hardware_concurrency()));
             if (n_threads == 1) match_leaves(0, n_nodes, pairs);
             else {
                 std::vector<std::vector<float>> part(n_threads);

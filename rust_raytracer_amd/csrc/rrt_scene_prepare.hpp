@@ -22,7 +22,8 @@ struct PreparedScene {
     uint64_t desc_hash = 0;     // of the description's arrays and camera
 };
 
-// Returns an RRT_* code (the message through rrt_set_error).
-int prepare_scene(const rrt_scene_desc* desc, PreparedScene* out);
+// Returns an RRT_* code (the message through rrt_set_error).  max_threads: 0 = as many as the machine offers, 16 at most (large
+// trees only; the result does not depend on it).
+int prepare_scene(const rrt_scene_desc* desc, PreparedScene* out, unsigned max_threads = 0);
 
 }  // namespace rrt

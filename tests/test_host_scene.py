@@ -564,6 +564,24 @@ def test_scene_description_whose_links_are_no_tree_is_refused():
     assert rc == 1 and "slot range" in msg
 
 
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_threaded_scene_preparation_is_race_free_and_equals_one_thread(tmp_path, sanitizer):
+    """Large trees are prepared for upload by several threads (rrt_scene_prepare.cpp).  tests/check_prepare_threads.cpp prepares a
+    131 071-node tree with one thread and with many, under ThreadSanitizer and under AddressSanitizer + UBSan: no report, and
+    the two results are the same bytes."""
+    import subprocess
+
+    exe = str(tmp_path / "check_prepare_threads")
+    csrc = os.path.join(ROOT, "rust_raytracer_amd", "csrc")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + sanitizer, "-fno-sanitize-recover=undefined", "-D__HIP_PLATFORM_AMD__",
+                           "-I", "/opt/rocm/include", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "check_prepare_threads.cpp"),
+                           os.path.join(csrc, "rrt_scene_prepare.cpp"), os.path.join(csrc, "rrt_error.cpp"), "-lpthread", "-o", exe])
+    env = dict(os.environ, ASAN_OPTIONS="verify_asan_link_order=0:detect_leaks=0", TSAN_OPTIONS="halt_on_error=1")
+    r = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "threads ok" in r.stdout and "WARNING" not in r.stderr
+
+
 def test_what_a_scene_would_upload_is_worked_out_without_a_device():
     """rrt_scene_check runs the CPU half of rrt_scene_create alone: the records, the kernel variant and the traversal choices of the
     shipped scenes and of synthetic ones, with no GPU in the box."""
