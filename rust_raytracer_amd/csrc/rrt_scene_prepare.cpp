@@ -188,7 +188,7 @@ std::vector<float> guard_table(const rrt_scene_desc* d, Pads pads) {
     for (uint32_t i = 0; i < d->n_boundary_tris; ++i) tris.push_back(&d->boundary_tris[i]);
     auto put_u = [](uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; };
     const float inf = std::numeric_limits<float>::infinity();
-    if (tris.empty()) return {0.0f, 0.0f, 0.0f, 0.0f, inf, inf, inf, put_u(2u), inf, 0.0f, 0.0f, 0.0f, inf, inf, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // nothing to graze
+    if (tris.empty()) return {0.0f, 0.0f, 0.0f, 0.0f, inf, inf, inf, put_u(0u), inf, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};  // nothing to graze
     double centre_d[3], radius = 0.0;
     triangle_sphere(d, centre_d, &radius);
     const float centre[3] = {(float)centre_d[0], (float)centre_d[1], (float)centre_d[2]};
@@ -262,7 +262,7 @@ std::vector<float> guard_table(const rrt_scene_desc* d, Pads pads) {
         }
         general.push_back(0.0f);
     }
-    while (general.size() < 8 || (general.size() / 4) % 2 != 0) {  // (the device takes two per turn, and the first two without asking)
+    while ((general.size() / 4) % 2 != 0) {  // (the device takes two per turn)
         const float inert[4] = {inf, 0.0f, 0.0f, 0.0f};  // d . G is infinite, or not a number: no ray is close to it
         general.insert(general.end(), inert, inert + 4);
     }
@@ -274,6 +274,7 @@ std::vector<float> guard_table(const rrt_scene_desc* d, Pads pads) {
     const float render_reach2 = std::nextafter((float)(render_reach * render_reach * 1.0001), inf);
     std::vector<float> out = {centre[0], centre[1], centre[2], rho, axis[0], axis[1], axis[2], put_u((uint32_t)(general.size() / 4)),
                               (float)longest_reach, render_reach2, put_u(own_reach ? 1u : 0u), 0.0f};
+    if (general.empty()) out.insert(out.end(), 8, 0.0f);  // (room for the two entries the device fetches with the header)
     for (size_t k = 0; k + 8 <= general.size(); k += 8) {  // two entries side by side: (x, x, y, y), (z, z, -, -)
         const float* a = &general[k];
         const float* b = &general[k + 4];

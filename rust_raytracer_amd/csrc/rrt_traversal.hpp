@@ -576,8 +576,8 @@ RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max
 // reference tests.  With the shallow trees' paddings that is about one ray in two thousand per plane direction.  Returns true for
 // such a ray (and for rays with non-finite or vanishing directions).
 // The table: (centre.xyz, rho); (gx, gy, gz, n) - the lengths of the entries along the three axes (infinite: none; most scenes'
-// walls) and the number of general entries, an even number and at least two (made up with entries no ray is close to:
-// (inf, 0, 0); a scene without triangles has only such entries); (longest reach, square of the reach of a ray that starts at the
+// walls) and the number of general entries, an even number (made up with an entry no ray is close to: (inf, 0, 0)) that may be
+// zero - the table still has room for two, which are fetched with the header -; (longest reach, square of the reach of a ray that starts at the
 // camera or on a primitive, flag, -); then the general entries, two to two float4: (x, x, y, y), (z, z, -, -).
 // ANY_ORIGIN = false (the render kernels, whose rays start at the camera or on a primitive) takes that one reach for every ray
 // instead of working out the ray's own, unless the flag is set: the host sets it when the one reach is too long to be useful (a
@@ -596,16 +596,18 @@ RRT_DEV v2f dot_two(f3 d, v4f xy, v4f z) {
 template <int AABB_MODE, bool ANY_ORIGIN>
 RRT_DEV bool grazes_a_plane(const DScene& sc, const Ray& r) {
     if (AABB_MODE == kAabbExhaustive) return false;  // (that mode has no shortcut to guard)
-    // (the header and the first two general entries - there are always two, inert ones if need be - are fetched together)
+    // (the header and the first two general entries are fetched together: the table always has room for two)
     const cv4p g = sc.c_guards();
     const v4f h0 = g[0], h1 = g[1], h2 = g[2], Gxy = g[3], Gz = g[4];
     const uint32_t n = __float_as_uint(h1.w);
     float m = min3_abs(__builtin_fabsf(r.d.x) * h1.x, r.d.y * h1.y, r.d.z * h1.z);
-    const v2f first = dot_two(r.d, Gxy, Gz);
-    m = min3_abs(m, first.x, first.y);
-    for (uint32_t j = 2; j < n; j += 2u) {
-        const v2f more = dot_two(r.d, g[3u + j], g[4u + j]);
-        m = min3_abs(m, more.x, more.y);
+    if (n != 0u) {  // (none in a scene whose triangles all lie across an axis: floors and walls)
+        const v2f first = dot_two(r.d, Gxy, Gz);
+        m = min3_abs(m, first.x, first.y);
+        for (uint32_t j = 2; j < n; j += 2u) {
+            const v2f more = dot_two(r.d, g[3u + j], g[4u + j]);
+            m = min3_abs(m, more.x, more.y);
+        }
     }
     const float dd = __builtin_fmaf(r.d.z, r.d.z, __builtin_fmaf(r.d.y, r.d.y, r.d.x * r.d.x));
     if (!ANY_ORIGIN && __float_as_uint(h2.z) == 0u) return !(m * m > dd * h2.y);
