@@ -197,7 +197,8 @@ std::vector<float> guard_table(const rrt_scene_desc* d, Pads pads) {
     // on a primitive
     double start2 = 0.0;
     for (int c = 0; c < 3; ++c) start2 += ((double)d->camera.origin[c] - centre_d[c]) * ((double)d->camera.origin[c] - centre_d[c]);
-    double start = std::sqrt(start2) + 2.0 * std::fabs((double)d->camera.lens_radius);
+    const double start_camera = std::sqrt(start2) + 2.0 * std::fabs((double)d->camera.lens_radius);
+    double start = 0.0;  // on a primitive
     for (uint32_t i = 0; i < d->n_slots; ++i) {
         float b[8];
         pair_box(d, i, 1, Pads{0.0f, 0.0f}, b);
@@ -269,11 +270,14 @@ std::vector<float> guard_table(const rrt_scene_desc* d, Pads pads) {
     // The render kernels take ONE reach for all their rays when that costs little: when the farthest start is within four radii of
     // the triangles' sphere (the Cornell boxes).  A small mesh in a wide scene (a cube on a ground sphere of a hundred times its
     // size) would have nearly every ray "graze" with the far ground's reach; there every ray works out its own.
-    const double render_reach = 1.001 * (start + (double)rho);
+    // Two of them: camera rays start at the camera (often far outside the scene: the Cornell boxes' stands 1.7 box widths in front),
+    // all later rays on a primitive, and the shorter reach of those lets a third fewer of them count as grazing.
+    const double render_reach = 1.001 * (std::fmax(start, start_camera) + (double)rho), bounce_reach = 1.001 * (start + (double)rho);
     const bool own_reach = !(render_reach <= 4.0 * (double)rho) || !(render_reach <= longest_reach);
     const float render_reach2 = std::nextafter((float)(render_reach * render_reach * 1.0001), inf);
+    const float bounce_reach2 = std::nextafter((float)(bounce_reach * bounce_reach * 1.0001), inf);
     std::vector<float> out = {centre[0], centre[1], centre[2], rho, axis[0], axis[1], axis[2], put_u((uint32_t)(general.size() / 4)),
-                              (float)longest_reach, render_reach2, put_u(own_reach ? 1u : 0u), 0.0f};
+                              (float)longest_reach, render_reach2, put_u(own_reach ? 1u : 0u), bounce_reach2};
     if (general.empty()) out.insert(out.end(), 8, 0.0f);  // (room for the two entries the device fetches with the header)
     for (size_t k = 0; k + 8 <= general.size(); k += 8) {  // two entries side by side: (x, x, y, y), (z, z, -, -)
         const float* a = &general[k];

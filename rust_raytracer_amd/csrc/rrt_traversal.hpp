@@ -578,8 +578,8 @@ RRT_DEV void sift_flush(const DScene& sc, const Ray& r, float t_min, float t_max
 // The table: (centre.xyz, rho); (gx, gy, gz, n) - the lengths of the entries along the three axes (infinite: none; most scenes'
 // walls) and the number of general entries, an even number (made up with an entry no ray is close to: (inf, 0, 0)) that may be
 // zero - the table still has room for two, which are fetched with the header -; (longest reach, square of the reach of a ray that starts at the
-// camera or on a primitive, flag, -); then the general entries, two to two float4: (x, x, y, y), (z, z, -, -).
-// ANY_ORIGIN = false (the render kernels, whose rays start at the camera or on a primitive) takes that one reach for every ray
+// camera or on a primitive, flag, the same for a ray that starts on a primitive: every ray of a path but its first); then the general entries, two to two float4: (x, x, y, y), (z, z, -, -).
+// ANY_ORIGIN = false (the render kernels, whose rays start at the camera or on a primitive) takes one of those two reaches
 // instead of working out the ray's own, unless the flag is set: the host sets it when the one reach is too long to be useful (a
 // small mesh in a wide scene) or longer than the longest reach.
 // (A direction too short for its squared length to be a normal float cannot hit a triangle at all: the reference's determinant
@@ -594,7 +594,7 @@ RRT_DEV v2f dot_two(f3 d, v4f xy, v4f z) {
     return __builtin_elementwise_fma(splat2(d.z), z.xy, __builtin_elementwise_fma(splat2(d.y), xy.zw, splat2(d.x) * xy.xy));
 }
 template <int AABB_MODE, bool ANY_ORIGIN>
-RRT_DEV bool grazes_a_plane(const DScene& sc, const Ray& r) {
+RRT_DEV bool grazes_a_plane(const DScene& sc, const Ray& r, bool from_camera) {
     if (AABB_MODE == kAabbExhaustive) return false;  // (that mode has no shortcut to guard)
     // (the header and the first two general entries are fetched together: the table always has room for two)
     const cv4p g = sc.c_guards();
@@ -610,7 +610,7 @@ RRT_DEV bool grazes_a_plane(const DScene& sc, const Ray& r) {
         }
     }
     const float dd = __builtin_fmaf(r.d.z, r.d.z, __builtin_fmaf(r.d.y, r.d.y, r.d.x * r.d.x));
-    if (!ANY_ORIGIN && __float_as_uint(h2.z) == 0u) return !(m * m > dd * h2.y);
+    if (!ANY_ORIGIN && __float_as_uint(h2.z) == 0u) return !(m * m > dd * (from_camera ? h2.y : h2.w));
     const float ox = r.o.x - h0.x, oy = r.o.y - h0.y, oz = r.o.z - h0.z;
     const float reach = __builtin_amdgcn_sqrtf(__builtin_fmaf(oz, oz, __builtin_fmaf(oy, oy, ox * ox))) + h0.w;
     const float lim2 = (dd * (reach * reach)) * 1.0001f;  // (the roundings of this function's own arithmetic)
@@ -633,7 +633,7 @@ RRT_DEV Hit closest_hit_sift(const DScene& sc, bool active, const Ray& r, float 
     uint32_t* items = (uint32_t*)(area + 64 * 8);
     // a ray that runs too close to a triangle's plane for the padded boxes to be trusted (see grazes_a_plane) gets NaN on all
     // three axes below: every pair box is then met, and so is every node's primitive box
-    const bool graze = grazes_a_plane<AABB_MODE, ANY_ORIGIN>(sc, r);
+    const bool graze = grazes_a_plane<AABB_MODE, ANY_ORIGIN>(sc, r, depth == 0u);
     const f3 inv = exact_rcp3(r.d);  // = 1.0f / r.d, bit for bit (see exact_rcp)
     // for the pair boxes: centre * finv + noi (see pair_box_overlap_ch); an axis whose product origin * inv is not finite (zero or
     // denormal direction component) gets NaN, which the interval test ignores: that axis then constrains nothing
