@@ -362,7 +362,10 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, con
                        loz = __float_as_uint(g2.x), hiz = __float_as_uint(g2.y);
         const uint32_t nx = dx ? hix : lox, fx = dx ? lox : hix, ny = dy ? hiy : loy, fy = dy ? loy : hiy, nz = dz ? hiz : loz, fz = dz ? loz : hiz;
         const uint32_t links[4] = {__float_as_uint(g2.z), __float_as_uint(g2.w), __float_as_uint(g3.x), __float_as_uint(g3.y)};
-        unsigned long long key[4];
+        // (order, link) of the children the ray meets, the others (kLinkNone) last; the exchanges compare the 32-bit order alone - a
+        // 64-bit compare on (order, link) costs a quarter-rate instruction and a wait per exchange, and which of two children at the
+        // same distance comes first changes nothing in a clean tree
+        uint32_t ord[4], lnk[4];
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const uint32_t link = links[k];
@@ -377,25 +380,29 @@ RRT_DEV void walk_step(const DScene& sc, Walk& w, const Ray& r, float t_min, con
             const bool met = entry <= leave && link != kLinkNone;
             // entry >= t_min: with a positive lower bound (a constant in the render kernels) the float's own bits order correctly
             const uint32_t order = t_min > 0.0f ? __float_as_uint(entry) : ord_bits(entry);
-            key[k] = met ? (((unsigned long long)order << 32) | link) : ~0ull;
+            ord[k] = met ? order : 0xffffffffu;
+            lnk[k] = met ? link : kLinkNone;
         }
-#define RRT_ORDER(a, b)                                   \
-    {                                                     \
-        const unsigned long long lo_ = a < b ? a : b;     \
-        b = a < b ? b : a;                                \
-        a = lo_;                                          \
+#define RRT_ORDER(i, j)                                    \
+    {                                                      \
+        const bool swap_ = ord[j] < ord[i];                \
+        const uint32_t oi_ = ord[i], li_ = lnk[i];         \
+        ord[i] = swap_ ? ord[j] : oi_;                     \
+        lnk[i] = swap_ ? lnk[j] : li_;                     \
+        ord[j] = swap_ ? oi_ : ord[j];                     \
+        lnk[j] = swap_ ? li_ : lnk[j];                     \
     }
-        RRT_ORDER(key[0], key[1]) RRT_ORDER(key[2], key[3]) RRT_ORDER(key[0], key[2]) RRT_ORDER(key[1], key[3]) RRT_ORDER(key[1], key[2])
+        RRT_ORDER(0, 1) RRT_ORDER(2, 3) RRT_ORDER(0, 2) RRT_ORDER(1, 3) RRT_ORDER(1, 2)
 #undef RRT_ORDER
-        if (key[0] == ~0ull) {
+        if (lnk[0] == kLinkNone) {
             if (w.sp == 0) w.running = false;
             else w.cur = stack_pop(stack, w.sp);
             return;
         }
-        w.cur = (uint32_t)key[0];
+        w.cur = lnk[0];
 #pragma unroll
         for (int k = 3; k >= 1; --k)
-            if (key[k] != ~0ull) stack_push(stack, w.sp, (uint32_t)key[k]);
+            if (lnk[k] != kLinkNone) stack_push(stack, w.sp, lnk[k]);
         return;
     }
     const v4f n0 = cnodes[4 * w.cur];
