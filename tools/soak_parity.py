@@ -45,4 +45,21 @@ for name, bg in (("Cornell_Box.json", rrt.BG_BLACK), ("Cornell_Box_With_Sphere.j
         print("%-30s %dx%d @ %d, %-9s: %d rays (oracle %d), %d of %d sums differ, %d NaN sums  %s" % (
             name, W, H, spp, label, st["rays"], int(st_ref[0]), int((~same).sum()), same.size, int(np.isnan(ref).sum()), "ok" if ok else "DIFFERENT"), flush=True)
     print("  (oracle: %.1f s on %d threads)" % (time.perf_counter() - t0, threads), flush=True)
+    # the ray-batch entry point: random rays from inside and around the scene, all three modes
+    bb = o.shape_bboxes()
+    extent = float(np.abs(bb[np.isfinite(bb).all(axis=1)]).max())
+    rng = np.random.default_rng(5)
+    n = 4_000_000
+    ro = rng.uniform(-1.5 * extent, 1.5 * extent, (n, 3)).astype(np.float32)
+    rd = rng.normal(size=(n, 3)).astype(np.float32)
+    rd[: n // 8, rng.integers(0, 3)] = 0.0  # some inside a coordinate plane
+    t1 = time.perf_counter()
+    p_ref, t_ref = o.intersect(ro, rd)
+    for mode, label in ((rrt.AABB_TIGHT, "tight"), (rrt.AABB_REFERENCE, "reference"), (rrt.AABB_EXHAUSTIVE, "exhaustive")):
+        p, t = scene.hit(ro, rd, aabb_mode=mode)
+        diff = int(((p != p_ref) | (t.view(np.uint32) != t_ref.view(np.uint32))).sum())
+        bad += 1 if diff else 0
+        print("%-30s %d random rays, %-10s: %d hits (oracle %d), %d answers differ  %s" % (name, n, label, int((p >= 0).sum()), int((p_ref >= 0).sum()), diff,
+                                                                                       "ok" if diff == 0 else "DIFFERENT"), flush=True)
+    print("  (oracle: %.1f s)" % (time.perf_counter() - t1), flush=True)
 sys.exit(1 if bad else 0)
